@@ -1,0 +1,94 @@
+"""ctypes binding of libaircraft_hip.so (include/aircraft_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or no gfx950 device is visible, every
+compute call raises.  (`tests -m "not gpu"` only check that the library loads and exports the ABI.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaircraft_hip.so")
+
+AC_OK = 0
+STATUS_NAMES = {0: "AC_OK", -1: "AC_ERR_BAD_ARG", -2: "AC_ERR_HIP", -3: "AC_ERR_UNSUPPORTED",
+                -4: "AC_ERR_NO_MODEL", -5: "AC_ERR_NO_DEVICE"}
+MODEL_KINDS = {"default": 0, "linear": 1, "nn": 2, "poly": 3}
+NUM_STATES = 13
+NUM_CONTROLS = 7
+AERO_ROWS = 20
+MAX_LAYERS = 8
+MAX_WIDTH = 128
+
+
+class AcParams(C.Structure):
+    """struct ac_params (include/aircraft_hip.h)."""
+    _fields_ = [
+        ("mass", C.c_float), ("S", C.c_float), ("b", C.c_float), ("c", C.c_float),
+        ("inertia", C.c_float * 9),
+        ("inertia_inv", C.c_float * 9),
+        ("com", C.c_float * 3),
+        ("rudder_moment_arm", C.c_float),
+        ("epsilon", C.c_float),
+        ("gravity", C.c_float * 3),
+        ("substeps", C.c_int), ("normalise", C.c_int), ("stall_scaling", C.c_int), ("model_kind", C.c_int),
+    ]
+
+
+# every symbol include/aircraft_hip.h declares, with its prototype
+_FP = C.POINTER(C.c_float)
+_VP = C.c_void_p
+PROTOTYPES = {
+    "ac_create": (C.c_int, [C.POINTER(AcParams), C.POINTER(_VP)]),
+    "ac_destroy": (C.c_int, [_VP]),
+    "ac_set_params": (C.c_int, [_VP, C.POINTER(AcParams)]),
+    "ac_set_linear": (C.c_int, [_VP, _FP]),
+    "ac_set_poly": (C.c_int, [_VP, _FP, _FP]),
+    "ac_set_mlp": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_FP), C.POINTER(_FP),
+                             _FP, _FP, _FP, _FP, C.c_int]),
+    "ac_state_derivative_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, _VP, _VP]),
+    "ac_step_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, _VP, _VP]),
+    "ac_rollout_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, C.c_long, C.c_long, _VP, _VP]),
+    "ac_step_sens_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, _VP, _VP, _VP, _VP, _VP]),
+    "ac_shoot_step_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, C.c_long, _VP, _VP]),
+    "ac_shoot_sens_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP, _VP]),
+    "ac_aero_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, _VP, _VP]),
+    "ac_traj_cost_f32": (C.c_int, [_VP, _VP, C.c_long, C.c_long, _FP, C.c_float, C.c_float, _VP, _VP]),
+    "ac_last_error": (C.c_char_p, []),
+    "ac_version": (C.c_char_p, []),
+    "ac_device_arch": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "ac_last_launch": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                 C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+class AircraftHipError(RuntimeError):
+    """Raised for any non-zero ac_status — the reference's failures surface as RuntimeError too
+    (control/base.py:471-474)."""
+
+
+def load():
+    """Load libaircraft_hip.so; raise (never fall back) if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AircraftHipError(
+                f"{LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). aircraft_amd has no CPU fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != AC_OK:
+        msg = load().ac_last_error().decode() if rc == -2 or rc == -3 or rc == -5 else ""
+        raise AircraftHipError(f"{what or 'aircraft_hip call'} failed: {STATUS_NAMES.get(rc, rc)} {msg}".strip())

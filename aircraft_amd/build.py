@@ -1,0 +1,59 @@
+"""Build libaircraft_hip.so in-tree with hipcc for gfx950 (no cmake/ninja, no JIT cache).
+One object per translation unit, compiled in parallel, then linked."""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+OBJ = os.path.join(_HERE, "csrc", "_obj")
+OUT = os.path.join(_HERE, "libaircraft_hip.so")
+HEADERS = glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(_HERE, "..", "include", "aircraft_hip.h")]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-pass-failed"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True, jobs: int | None = None) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    todo = []
+    objs = []
+    for src in sources():
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + HEADERS):
+            todo.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = ["hipcc", *CFLAGS, "-c", src, "-o", obj]
+        if verbose:
+            print("[aircraft_amd.build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+            list(ex.map(cc, todo))
+    if todo or force or _stale(OUT, objs):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", OUT, *objs]
+        if verbose:
+            print("[aircraft_amd.build]", " ".join(cmd[:6]), f"... ({len(objs)} objects)", flush=True)
+        subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

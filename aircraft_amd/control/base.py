@@ -1,0 +1,122 @@
+"""Multiple-shooting loop over the batched dynamics — the part of the reference's `ControlProblem`
+(src/aircraft/control/base.py:123-443) that sits ON the hot path:
+
+    self.dynamics = system.state_update ; state_dim / control_dim from size1_in      base.py:187-190
+    system.normalise = (opts['quaternion'] == 'integration')                         base.py:182-185
+    defect rows  x_{k+1} - F(x_k, u_k, dt_k) = 0  for k = 0..N-1                      base.py:275-286, 423-443
+    dt_k = 1 / progress_k**2                                                          base.py:276
+    rollout initial guess  guess[:, i+1] = dynamics(guess[:13, i], guess[13:, i], dt) main/control/control.py:72-93
+
+The NLP itself (Opti/IPOPT) is out of scope; what is built here are the residual and Jacobian blocks
+the solver's nlp_g / nlp_jac_g evaluate, for B independent instances at once.
+Trajectory buffers are rollout-shaped device tensors X (N+1, 13, B), U (N, 7, B), used in place.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from .. import _lib
+from ..dynamics.base import SixDOF
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+class MultipleShooting:
+    def __init__(self, *, system: SixDOF, dt: float = 0.01, num_nodes: int, opts: Optional[dict] = None, **kwargs):
+        self.opts = opts if opts else {}
+        # same side effect as the reference constructor (control/base.py:182-185)
+        system.normalise = self.opts.get("quaternion", None) == "integration"
+        self.system = system
+        self.dynamics = system.state_update
+        self.state_dim: int = self.dynamics.size1_in(0)
+        self.control_dim: int = self.dynamics.size1_in(1)
+        self.x_dot = system.state_derivative
+        self.num_nodes = num_nodes
+        self.dt = dt
+
+    # ---- time handling ---------------------------------------------------------------------------
+    @staticmethod
+    def dt_from_progress(progress):
+        """dt_k = 1 / progress_k^2  (control/base.py:276); fixed time uses progress = sqrt(1/dt) (:350)."""
+        return 1.0 / (progress * progress)
+
+    # ---- rollout (HOT LOOP #1) -------------------------------------------------------------------
+    def rollout(self, x0, U, out=None):
+        """x0 (13, B), U (N, 7, B) -> X (N+1, 13, B) on the device."""
+        return self.system.rollout(x0, U, self.dt, out=out)
+
+    def initialise(self, initial_state, controls=None):
+        """Reference-shaped initial guess for ONE instance: array (state_dim + control_dim, N+1) whose state rows
+        are the rollout of the control rows (main/control/control.py:72-93: aileron guess 1, elevator 0)."""
+        N = self.num_nodes
+        guess = np.zeros((self.state_dim + self.control_dim, N + 1))
+        if controls is None:
+            guess[13, :] = 1
+            guess[14, :] = 0
+        else:
+            guess[self.state_dim:, :] = np.asarray(controls, dtype=np.float64).reshape(self.control_dim, N + 1)
+        x0 = np.asarray(initial_state, dtype=np.float64).reshape(self.state_dim)
+        U = np.ascontiguousarray(guess[self.state_dim:, :N].T[:, :, None])  # (N, 7, 1)
+        traj = self.system.rollout(x0[:, None], U, self.dt)  # numpy in -> numpy out, (N+1, 13, 1)
+        guess[: self.state_dim, :] = traj[:, :, 0].T
+        return guess
+
+    # ---- defects and their Jacobian blocks (HOT LOOPS #2/#3) ---------------------------------------
+    def _shoot_args(self, X, U, dt):
+        torch = _torch()
+        H, B = U.shape[0], U.shape[2]
+        assert X.is_cuda and U.is_cuda and X.dtype == torch.float32 and U.dtype == torch.float32
+        assert X.is_contiguous() and U.is_contiguous()
+        assert X.shape[0] >= H and X.shape[1] == self.state_dim and X.shape[2] == B and U.shape[1] == self.control_dim
+        if dt is None:
+            dt = self.dt
+        if isinstance(dt, torch.Tensor) and dt.numel() > 1:
+            dtt = dt.to(device=X.device, dtype=torch.float32).contiguous()
+            assert dtt.shape == (H, B)
+            return H, B, C.c_float(0.0), C.c_void_p(dtt.data_ptr()), dtt
+        return H, B, C.c_float(float(dt)), C.c_void_p(0), None
+
+    def propagate(self, X, U, dt=None, out=None):
+        """F(x_k, u_k, dt_k) for every node k < N of every instance: (N, 13, B)."""
+        torch = _torch()
+        lib = self.system._sync()
+        H, B, dts, dtp, keep = self._shoot_args(X, U, dt)
+        if out is None:
+            out = torch.empty((H, self.state_dim, B), device=X.device, dtype=torch.float32)
+        _lib.check(lib.ac_shoot_step_f32(self.system._handle, X.data_ptr(), U.data_ptr(), dts, dtp, B, H,
+                                         out.data_ptr(), self.system._stream()), "ac_shoot_step_f32")
+        del keep
+        return out
+
+    def defects(self, X, U, dt=None):
+        """r_k = x_{k+1} - F(x_k, u_k, dt_k), (N, 13, B)  (control/base.py:279-280)."""
+        H = U.shape[0]
+        return X[1 : H + 1] - self.propagate(X, U, dt)
+
+    def linearise(self, X, U, dt=None, want_c=True, out=None):
+        """(F, A, B, c) per node: F (N,13,B), A = dF/dx (N,13,13,B), B = dF/du (N,13,7,B), c = dF/ddt (N,13,B).
+        The defect Jacobian rows are [-A_k, -B_k, I] (and -c_k * d(dt_k)/d(progress_k) in progress time)."""
+        torch = _torch()
+        lib = self.system._sync()
+        H, B, dts, dtp, keep = self._shoot_args(X, U, dt)
+        ns, nc = self.state_dim, self.control_dim
+        if out is None:
+            F = torch.empty((H, ns, B), device=X.device, dtype=torch.float32)
+            A = torch.empty((H, ns, ns, B), device=X.device, dtype=torch.float32)
+            Bm = torch.empty((H, ns, nc, B), device=X.device, dtype=torch.float32)
+            c = torch.empty((H, ns, B), device=X.device, dtype=torch.float32) if want_c else None
+        else:
+            F, A, Bm, c = out
+        _lib.check(lib.ac_shoot_sens_f32(self.system._handle, X.data_ptr(), U.data_ptr(), dts, dtp, B, H,
+                                         F.data_ptr(), A.data_ptr(), Bm.data_ptr(),
+                                         c.data_ptr() if c is not None else None, self.system._stream()),
+                   "ac_shoot_sens_f32")
+        del keep
+        return F, A, Bm, c

@@ -1,0 +1,262 @@
+// ac_kernels_analytic.hpp — kernels for the analytic coefficient models (default / linear / poly).
+//
+// Layouts (all fp32, component-major): X [13][n], U [7][n], Xn [13][n], A [13][13][n], Bm [13][7][n],
+// c [13][n]; rollout U [H][7][B], Xout [H+1][13][B].  Consecutive lanes own consecutive units, so
+// every global access is a contiguous 256-B (forward) or 64-B (4-lanes-per-unit) segment per row.
+#pragma once
+#include "ac_dynamics.hpp"
+
+namespace ac {
+
+constexpr int kBlock = 256;
+
+// Blocked component-major addressing.  Unit u = q*blk + r lives at [q][row][r] of an array
+// [n/blk][ROWS][blk].  blk == n is the flat [ROWS][n] case; blk == B addresses rollout-shaped buffers
+// ([H][ROWS][B]: q = node, r = instance) in place, so multiple-shooting callers need no transpose.
+struct UnitAddr {
+    long q, r, blk;
+    AC_DI UnitAddr(long u, long blk_) : q(u / blk_), r(u % blk_), blk(blk_) {}
+    AC_DI long off(int rows) const { return q * rows * blk + r; }
+};
+
+template <int ROWS> AC_DI void load_rows(const float* __restrict__ src, const UnitAddr& ua, float out[ROWS]) {
+    const float* p = src + ua.off(ROWS);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) out[r] = p[(long)r * ua.blk];
+}
+template <int ROWS> AC_DI void store_rows(float* __restrict__ dst, const UnitAddr& ua, const float v[ROWS]) {
+    float* p = dst + ua.off(ROWS);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) p[(long)r * ua.blk] = v[r];
+}
+// flat [ROWS][n] helper used by the rollout kernels
+template <int ROWS> AC_DI void load_rows(const float* __restrict__ src, long n, long i, float out[ROWS]) {
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) out[r] = src[(long)r * n + i];
+}
+
+// ---- forward kernels: one lane per unit ------------------------------------------------------
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void k_state_derivative(const DevParams P, const float* __restrict__ X,
+                                                             const float* __restrict__ U, long n, long blk,
+                                                             float* __restrict__ Xdot) {
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const UnitAddr ua(i, blk);
+    float x[13], u[7], xd[13];
+    load_rows<13>(X, ua, x);
+    load_rows<7>(U, ua, u);
+    AnalyticCoeffs<MODEL> coeffs;
+    coeffs.prefetch(P, x, u);
+    state_derivative<float>(P, coeffs, x, u, xd);
+    store_rows<13>(Xdot, ua, xd);
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void k_step(const DevParams P, const float* __restrict__ X,
+                                                 const float* __restrict__ U, float dt,
+                                                 const float* __restrict__ dt_per_unit, long n, long blk,
+                                                 float* __restrict__ Xn) {
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const UnitAddr ua(i, blk);
+    float x[13], u[7];
+    load_rows<13>(X, ua, x);
+    load_rows<7>(U, ua, u);
+    const float h = dt_per_unit ? dt_per_unit[i] : dt;
+    AnalyticCoeffs<MODEL> coeffs;
+    state_update(P, coeffs, x, u, h);
+    store_rows<13>(Xn, ua, x);
+}
+
+// Sequential-in-k rollout: the state stays in registers, u_k streams in, x_{k+1} streams out
+// (28 B read + 52 B written per horizon step).
+template <int MODEL>
+__global__ __launch_bounds__(64) void k_rollout(const DevParams P, const float* __restrict__ X0,
+                                                const float* __restrict__ U, float dt, long B, long H,
+                                                float* __restrict__ Xout) {
+    const long i = (long)blockIdx.x * 64 + threadIdx.x;
+    if (i >= B) return;
+    float x[13], u[7], un[7];
+    load_rows<13>(X0, B, i, x);
+    double xa[13];  // float64 carry of the state across the horizon (see state_update_carry)
+#pragma unroll
+    for (int r = 0; r < 13; ++r) { Xout[(long)r * B + i] = x[r]; xa[r] = (double)x[r]; }
+    if (H > 0) load_rows<7>(U, B, i, u);
+    AnalyticCoeffs<MODEL> coeffs;
+    for (long k = 0; k < H; ++k) {
+        if (k + 1 < H) load_rows<7>(U + (k + 1) * 7 * B, B, i, un);  // prefetch next control
+        state_update_carry(P, coeffs, xa, u, dt);
+        float* o = Xout + (k + 1) * 13 * B;
+#pragma unroll
+        for (int r = 0; r < 13; ++r) o[(long)r * B + i] = (float)xa[r];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) u[r] = un[r];
+    }
+}
+
+// Aerodynamic getters (v_frd_rel, airspeed, alpha, beta, qbar, coefficients, forces_frd, moments_frd)
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void k_aero(const DevParams P, const float* __restrict__ X,
+                                                 const float* __restrict__ U, long n, long blk,
+                                                 float* __restrict__ out) {
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const UnitAddr ua(i, blk);
+    float x[13], u[7];
+    load_rows<13>(X, ua, x);
+    load_rows<7>(U, ua, u);
+    AeroPre<float> a;
+    aero_pre(P, x, a);
+    float C[6];
+    AnalyticCoeffs<MODEL> coeffs;
+    coeffs.prefetch(P, x, u);
+    coeffs(P, a, x, u, C);
+    AeroPost<float> o;
+    aero_post(P, a, u, C, o);
+    const float v[20] = {a.vr[0], a.vr[1], a.vr[2], a.V, a.alpha, a.beta, a.qbar, o.C[0], o.C[1], o.C[2],
+                         o.C[3], o.C[4], o.C[5], o.F[0], o.F[1], o.F[2], o.M[0], o.M[1], o.M[2], 0.f};
+    store_rows<20>(out, ua, v);
+}
+
+// ---- sensitivities (direction layout: ac_dynamics.hpp, struct Seeds) ------------------------------
+struct SensIO {
+    // column of this lane's direction j in the output arrays: base pointer + row stride (null = no column)
+    static AC_DI void column(int d, long n, float* Au, float* Bu, float* cu, float*& base, long& stride) {
+        if (d < 10) { base = Au + (long)(3 + d) * n; stride = 13 * n; }
+        else if (d < 13) { base = Bu + (long)(d - 10) * n; stride = 7 * n; }
+        else if (d == 13) { base = Bu + 6L * n; stride = 7 * n; }
+        else if (d == 14) { base = cu; stride = n; }
+        else { base = nullptr; stride = 0; }
+    }
+
+    // Store this lane's four tangent columns of the 13 outputs (+ its share of the constant columns).
+    static AC_DI void store(int g, const UnitAddr& ua, const Dual<4> x[13], float* __restrict__ A,
+                            float* __restrict__ Bm, float* __restrict__ c, bool constants) {
+        const long n = ua.blk;  // row stride
+        float* Au = A + ua.off(169);
+        float* Bu = Bm + ua.off(91);
+        float* cu = c ? c + ua.off(13) : nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float* base; long stride;
+            column(4 * g + j, n, Au, Bu, cu, base, stride);
+            if (base) {
+#pragma unroll
+                for (int i = 0; i < 13; ++i) base[(long)i * stride] = x[i].d[j];
+            }
+        }
+        if (constants && g < 3) {
+#pragma unroll
+            for (int i = 0; i < 13; ++i) {
+                Au[((long)i * 13 + g) * n] = (i == g) ? 1.f : 0.f;  // dF/dp_g
+                Bu[((long)i * 7 + 3 + g) * n] = 0.f;               // dF/dthrust_g
+            }
+        }
+    }
+
+    // Read back the columns this lane stored earlier (sub-step composition only).
+    static AC_DI void load(int g, const UnitAddr& ua, Dual<4> x[13], const float* A, const float* Bm,
+                           const float* c) {
+        const long n = ua.blk;
+        float* Au = const_cast<float*>(A) + ua.off(169);
+        float* Bu = const_cast<float*>(Bm) + ua.off(91);
+        float* cu = c ? const_cast<float*>(c) + ua.off(13) : nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float* base; long stride;
+            column(4 * g + j, n, Au, Bu, cu, base, stride);
+#pragma unroll
+            for (int i = 0; i < 13; ++i) x[i].d[j] = base ? base[(long)i * stride] : 0.f;
+        }
+    }
+};
+
+// The whole sensitivity step for one unit spread over four lanes (g = 0..3).  Wave-collective when the
+// coefficient provider is (MLP engine) and always for substeps > 1 (cross-lane composition).
+//
+// substeps == 1 (every MPC driver of the reference): one seeded RK4 step, tangents stay in registers.
+// substeps  > 1: each sub-step is seeded on its own (local Jacobian T_s w.r.t. its inputs) and composed with
+// the running total  T <- dF_s/dx . T + dF_s/d(u, dt)  kept in the OUTPUT arrays between sub-steps, so the
+// register footprint of the hot path is not paid for by the rare one.
+template <class Coeffs>
+AC_DI void sens_update(const DevParams& P, Coeffs& coeffs, int g, int col, const UnitAddr& ua, float xv[13],
+                       const float uv[7], float dt, Dual<4> x[13], float* __restrict__ A, float* __restrict__ Bm,
+                       float* __restrict__ c, bool live) {
+    const int ns = P.p.substeps < 1 ? 1 : P.p.substeps;
+    const float hv = (ns == 1) ? dt : dt / (float)ns;
+    const float dh = 1.0f / (float)ns;
+#pragma nounroll
+    for (int s = 0; s < ns; ++s) {
+        rk4_step_seeded(P, coeffs, g, xv, uv, hv, dh, x);
+        if (ns > 1) {
+            if (s > 0) {
+                Dual<4> told[13], tnew[13];
+                if (live) SensIO::load(g, ua, told, A, Bm, c);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 13; ++i) told[i] = Dual<4>(0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < 13; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // direct dependence of this sub-step on (u, dt); state directions chain only
+                        float t = (4 * g + j >= 10) ? x[i].d[j] : 0.f;
+                        if (i < 3) t += told[i].d[j];  // dF_s/dp = [I; 0]
+                        tnew[i].d[j] = t;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+#pragma unroll
+                    for (int i = 0; i < 13; ++i) {
+                        const float a_ik = __shfl(x[i].d[k & 3], col + 16 * (k >> 2), 64);  // dF_s[i]/dx[3+k]
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) tnew[i].d[j] = fmaf(a_ik, told[3 + k].d[j], tnew[i].d[j]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 13; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[i].d[j] = tnew[i].d[j];
+                }
+            }
+            if (live) SensIO::store(g, ua, x, A, Bm, c, false);
+            __builtin_amdgcn_s_waitcnt(0);  // own stores retired before the next sub-step reads them back
+#pragma unroll
+            for (int i = 0; i < 13; ++i) xv[i] = x[i].v;
+        }
+    }
+    if (P.p.normalise) normalise_q(x);
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void k_step_sens(const DevParams P, const float* __restrict__ X,
+                                                      const float* __restrict__ U, float dt,
+                                                      const float* __restrict__ dt_per_unit, long n, long blk,
+                                                      float* __restrict__ Xn, float* __restrict__ A,
+                                                      float* __restrict__ Bm, float* __restrict__ c) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, g = lane >> 4;
+    const long unit_raw = ((long)blockIdx.x * (kBlock / 64) + wave) * 16 + col;
+    const bool live = unit_raw < n;
+    const long unit = live ? unit_raw : n - 1;  // clamp: dead lanes recompute the last unit, store nothing
+    const UnitAddr ua(unit, blk);
+    float xv[13], uv[7];
+    load_rows<13>(X, ua, xv);
+    load_rows<7>(U, ua, uv);
+    const float hv = dt_per_unit ? dt_per_unit[unit] : dt;
+    Dual<4> x[13];
+    AnalyticCoeffs<MODEL> coeffs;
+    sens_update(P, coeffs, g, col, ua, xv, uv, hv, x, A, Bm, c, live);
+    if (!live) return;
+    if (g == 0) {
+        float* p = Xn + ua.off(13);
+#pragma unroll
+        for (int i = 0; i < 13; ++i) p[(long)i * blk] = x[i].v;
+    }
+    SensIO::store(g, ua, x, A, Bm, c, true);
+}
+
+}  // namespace ac

@@ -1,0 +1,133 @@
+// ac_kernels_nn.hpp — kernels for the MLP surrogate ("nn") model, built on the wave-level engine of
+// ac_mlp.hpp.  One wave = 16 units (col = lane & 15), four lanes per unit (g = lane >> 4).
+//   * sensitivities: the four lanes carry four tangent directions each (Dual<4>), the engine runs
+//     6 slabs (value + 5 input tangents) -> the fused step+Jacobian kernel, the headline hot path.
+//   * forward (derivative / step / rollout / aero): the four lanes of a unit compute the same values
+//     (the rigid-body part is <3 % of the work); the engine runs the value slab only.
+#pragma once
+#include "ac_kernels_analytic.hpp"
+#include "ac_mlp.hpp"
+
+namespace ac {
+
+enum FwdOp { OP_DERIV = 0, OP_STEP = 1, OP_AERO = 2 };
+
+struct WaveUnit {
+    int lane, col, g;
+    long unit;
+    bool live;
+    UnitAddr ua;
+    AC_DI static long raw_unit() {
+        return ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 15);
+    }
+    // dead lanes shadow the last unit so wave/workgroup collectives stay uniform
+    AC_DI WaveUnit(long n, long blk)
+        : lane(threadIdx.x & 63), col(threadIdx.x & 15), g((threadIdx.x & 63) >> 4),
+          unit(raw_unit() < n ? raw_unit() : n - 1), live(raw_unit() < n), ua(unit, blk) {}
+};
+
+template <int WT, bool USE_MFMA>
+__global__ __launch_bounds__(kBlock, 1) void k_nn_step_sens(const DevParams P, const MlpPlan plan,
+                                                            const float* __restrict__ blob,
+                                                            const float* __restrict__ X, const float* __restrict__ U,
+                                                            float dt, const float* __restrict__ dt_per_unit, long n, long blk,
+                                                            float* __restrict__ Xn, float* __restrict__ A,
+                                                            float* __restrict__ Bm, float* __restrict__ c) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MlpEngine<6, WT, USE_MFMA> eng(plan, blob, smem);
+    eng.load_weights();
+    const WaveUnit w(n, blk);
+    float xv[13], uv[7];
+    load_rows<13>(X, w.ua, xv);
+    load_rows<7>(U, w.ua, uv);
+    const float hv = dt_per_unit ? dt_per_unit[w.unit] : dt;
+    Dual<4> x[13];
+    MlpCoeffs<MlpEngine<6, WT, USE_MFMA>> coeffs(eng);
+    sens_update(P, coeffs, w.g, w.col, w.ua, xv, uv, hv, x, A, Bm, c, w.live);
+    eng.drain();
+    if (!w.live) return;
+    if (w.g == 0) {
+        float* p = Xn + w.ua.off(13);
+#pragma unroll
+        for (int i = 0; i < 13; ++i) p[(long)i * blk] = x[i].v;
+    }
+    SensIO::store(w.g, w.ua, x, A, Bm, c, true);
+}
+
+template <int WT, bool USE_MFMA, int OP>
+__global__ __launch_bounds__(kBlock, 1) void k_nn_fwd(const DevParams P, const MlpPlan plan,
+                                                      const float* __restrict__ blob, const float* __restrict__ X,
+                                                      const float* __restrict__ U, float dt,
+                                                      const float* __restrict__ dt_per_unit, long n, long blk,
+                                                      float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MlpEngine<1, WT, USE_MFMA> eng(plan, blob, smem);
+    eng.load_weights();
+    const WaveUnit w(n, blk);
+    float x[13], u[7];
+    load_rows<13>(X, w.ua, x);
+    load_rows<7>(U, w.ua, u);
+    MlpCoeffs<MlpEngine<1, WT, USE_MFMA>> coeffs(eng);
+    if constexpr (OP == OP_DERIV) {
+        float xd[13];
+        coeffs.prefetch(P, x, u);
+    state_derivative<float>(P, coeffs, x, u, xd);
+        eng.drain();
+        if (w.live && w.g == 0) store_rows<13>(out, w.ua, xd);
+    } else if constexpr (OP == OP_STEP) {
+        const float h = dt_per_unit ? dt_per_unit[w.unit] : dt;
+        state_update(P, coeffs, x, u, h);
+        eng.drain();
+        if (w.live && w.g == 0) store_rows<13>(out, w.ua, x);
+    } else {
+        coeffs.prefetch(P, x, u);
+        AeroPre<float> a;
+        aero_pre(P, x, a);
+        float C[6];
+        coeffs(P, a, x, u, C);
+        AeroPost<float> o;
+        aero_post(P, a, u, C, o);
+        eng.drain();
+        const float v[20] = {a.vr[0], a.vr[1], a.vr[2], a.V, a.alpha, a.beta, a.qbar, o.C[0], o.C[1], o.C[2],
+                             o.C[3], o.C[4], o.C[5], o.F[0], o.F[1], o.F[2], o.M[0], o.M[1], o.M[2], 0.f};
+        if (w.live && w.g == 0) store_rows<20>(out, w.ua, v);
+    }
+}
+
+// Sequential rollout: one wave (16 instances) per workgroup so B = 4096 spreads over 256 CUs.
+template <int WT, bool USE_MFMA>
+__global__ __launch_bounds__(64, 1) void k_nn_rollout(const DevParams P, const MlpPlan plan,
+                                                      const float* __restrict__ blob, const float* __restrict__ X0,
+                                                      const float* __restrict__ U, float dt, long B, long H,
+                                                      float* __restrict__ Xout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MlpEngine<1, WT, USE_MFMA> eng(plan, blob, smem);
+    eng.load_weights();
+    const WaveUnit w(B, B);
+    float x[13], u[7], un[7];
+    load_rows<13>(X0, B, w.unit, x);
+    const bool writer = w.live && w.g == 0;
+    double xa[13];  // float64 carry of the state across the horizon (see state_update_carry)
+#pragma unroll
+    for (int r = 0; r < 13; ++r) xa[r] = (double)x[r];
+    if (writer) {
+#pragma unroll
+        for (int r = 0; r < 13; ++r) Xout[(long)r * B + w.unit] = x[r];
+    }
+    if (H > 0) load_rows<7>(U, B, w.unit, u);
+    MlpCoeffs<MlpEngine<1, WT, USE_MFMA>> coeffs(eng);
+    for (long k = 0; k < H; ++k) {
+        if (k + 1 < H) load_rows<7>(U + (k + 1) * 7 * B, B, w.unit, un);
+        state_update_carry(P, coeffs, xa, u, dt);
+        if (writer) {
+            float* o = Xout + (k + 1) * 13 * B;
+#pragma unroll
+            for (int r = 0; r < 13; ++r) o[(long)r * B + w.unit] = (float)xa[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 7; ++r) u[r] = un[r];
+    }
+    eng.drain();
+}
+
+}  // namespace ac

@@ -1,0 +1,139 @@
+// ac_math.hpp — scalar / forward-mode-dual arithmetic used by every kernel (gfx950, fp32).
+//
+// The rigid-body code in ac_dynamics.hpp is templated on the scalar type T:
+//   T = float      : values only (forward step / rollout)
+//   T = Dual<N>    : value + N tangent directions (step sensitivities; N = 4, four lanes per unit)
+// Tangent directions are independent given the primal, so a unit's 15 non-trivial directions
+// (v, q, omega, 4 active controls, dt) are spread over 4 lanes x Dual<4>.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ac {
+
+template <int N>
+struct Dual {
+    float v;
+    float d[N];
+    __device__ __forceinline__ Dual() {}
+    __device__ __forceinline__ Dual(float x) : v(x) {  // NOLINT (implicit on purpose)
+#pragma unroll
+        for (int i = 0; i < N; ++i) d[i] = 0.f;
+    }
+};
+
+#define AC_DI __device__ __forceinline__
+
+template <int N> AC_DI Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) {
+    Dual<N> r; r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i];
+    return r;
+}
+template <int N> AC_DI Dual<N> operator-(const Dual<N>& a, const Dual<N>& b) {
+    Dual<N> r; r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i];
+    return r;
+}
+template <int N> AC_DI Dual<N> operator-(const Dual<N>& a) {
+    Dual<N> r; r.v = -a.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = -a.d[i];
+    return r;
+}
+template <int N> AC_DI Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) {
+    Dual<N> r; r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = fmaf(a.d[i], b.v, a.v * b.d[i]);
+    return r;
+}
+template <int N> AC_DI Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) {
+    Dual<N> r; const float inv = 1.0f / b.v; r.v = a.v * inv;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+    return r;
+}
+template <int N> AC_DI Dual<N> operator+(const Dual<N>& a, float b) { Dual<N> r = a; r.v += b; return r; }
+template <int N> AC_DI Dual<N> operator+(float b, const Dual<N>& a) { Dual<N> r = a; r.v += b; return r; }
+template <int N> AC_DI Dual<N> operator-(const Dual<N>& a, float b) { Dual<N> r = a; r.v -= b; return r; }
+template <int N> AC_DI Dual<N> operator-(float b, const Dual<N>& a) { Dual<N> r = -a; r.v += b; return r; }
+template <int N> AC_DI Dual<N> operator*(const Dual<N>& a, float b) {
+    Dual<N> r; r.v = a.v * b;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b;
+    return r;
+}
+template <int N> AC_DI Dual<N> operator*(float b, const Dual<N>& a) { return a * b; }
+template <int N> AC_DI Dual<N> operator/(const Dual<N>& a, float b) { return a * (1.0f / b); }
+template <int N> AC_DI Dual<N> operator/(float a, const Dual<N>& b) {
+    Dual<N> r; const float inv = 1.0f / b.v; r.v = a * inv; const float g = -r.v * inv;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = g * b.d[i];
+    return r;
+}
+
+AC_DI float value_of(float x) { return x; }
+template <int N> AC_DI float value_of(const Dual<N>& x) { return x.v; }
+
+AC_DI float m_sqrt(float x) { return sqrtf(x); }
+template <int N> AC_DI Dual<N> m_sqrt(const Dual<N>& a) {
+    Dual<N> r; r.v = sqrtf(a.v); const float g = 0.5f / r.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * g;
+    return r;
+}
+AC_DI float m_atan2(float y, float x) { return atan2f(y, x); }
+template <int N> AC_DI Dual<N> m_atan2(const Dual<N>& y, const Dual<N>& x) {
+    Dual<N> r; r.v = atan2f(y.v, x.v); const float den = 1.0f / fmaf(x.v, x.v, y.v * y.v);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = (x.v * y.d[i] - y.v * x.d[i]) * den;
+    return r;
+}
+AC_DI float m_asin(float x) { return asinf(x); }
+template <int N> AC_DI Dual<N> m_asin(const Dual<N>& a) {
+    Dual<N> r; r.v = asinf(a.v); const float g = 1.0f / sqrtf(fmaf(-a.v, a.v, 1.0f));
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * g;
+    return r;
+}
+AC_DI float m_exp(float x) { return expf(x); }
+template <int N> AC_DI Dual<N> m_exp(const Dual<N>& a) {
+    Dual<N> r; r.v = expf(a.v);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * r.v;
+    return r;
+}
+AC_DI float m_fabs(float x) { return fabsf(x); }
+template <int N> AC_DI Dual<N> m_fabs(const Dual<N>& a) { return a.v < 0.f ? -a : a; }
+// casadi sign(): -1 / 0 / +1 (NaN propagates); derivative identically zero
+AC_DI float sign_of(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : (x == 0.f ? 0.f : x)); }
+
+// xyzw quaternion, Hamilton product (liecasadi convention fixed by the simulation.h5 replay)
+template <class T> struct Q4 { T x, y, z, w; };
+
+template <class T> AC_DI Q4<T> qmul(const Q4<T>& a, const Q4<T>& b) {
+    Q4<T> r;
+    r.x = a.w * b.x + b.w * a.x + (a.y * b.z - a.z * b.y);
+    r.y = a.w * b.y + b.w * a.y + (a.z * b.x - a.x * b.z);
+    r.z = a.w * b.z + b.w * a.z + (a.x * b.y - a.y * b.x);
+    r.w = a.w * b.w - (a.x * b.x + a.y * b.y + a.z * b.z);
+    return r;
+}
+// q (x) (v, 0): the pure-vector right factor saves the w-terms
+template <class T> AC_DI Q4<T> qmul_vec(const Q4<T>& a, const T& bx, const T& by, const T& bz) {
+    Q4<T> r;
+    r.x = a.w * bx + (a.y * bz - a.z * by);
+    r.y = a.w * by + (a.z * bx - a.x * bz);
+    r.z = a.w * bz + (a.x * by - a.y * bx);
+    r.w = -(a.x * bx + a.y * by + a.z * bz);
+    return r;
+}
+// inverse = conjugate / |q|^2   (dynamics/base.py:158 via liecasadi Quaternion.inverse)
+template <class T> AC_DI Q4<T> qinv(const Q4<T>& q) {
+    const T n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    const T inv = 1.0f / n2;
+    Q4<T> r; r.x = -(q.x * inv); r.y = -(q.y * inv); r.z = -(q.z * inv); r.w = q.w * inv;
+    return r;
+}
+
+}  // namespace ac

@@ -1,0 +1,288 @@
+// ac_mlp.hpp — wave-level MLP surrogate engine for gfx950 (the NeuralModel of
+// dynamics/coefficient_models.py:91-104 / ScaledModel of surrogates/models.py:101-155).
+//
+// Data layout (one wave = 16 units, 4 lanes per unit: col = lane & 15 is the unit, g = lane >> 4):
+//   * An activation "slab" is a [width][16 units] fp32 matrix held ENTIRELY IN REGISTERS in the
+//     C/D layout of v_mfma_f32_16x16x4_f32: register a[s][t][r] of lane (col, g) is row 16 t + 4 g + r,
+//     column `col`.  A D tile in that layout is *directly* the B operand of the next layer's MFMA
+//     (k-step r of k-tile t multiplies rows {16t+r, 16t+4+r, 16t+8+r, 16t+12+r}), so activations never
+//     leave the register file between layers — no LDS round trip, no shuffles.
+//   * The matching A operand for (out-tile nt, k-tile kt, k-step r) is W[16 nt + col][16 kt + 4 g + r]:
+//     the host packs each layer in "fragment order" [nt][kt][lane][4] so that one conflict-free
+//     ds_read_b128 at base + 16*lane fetches the A operands of all four k-steps.
+//   * Slab 0 carries values.  In tangent mode slabs 1..5 carry d/d(input j) — forward-mode through
+//     the net: t_out = act'(h_out) * (W t_in).  The 6 x 128 x 16 fp32 activations of a 4x128 net are
+//     192 registers per lane; the output tile of the slab being computed adds 32.
+//   * Weights: layers that fit stay resident in LDS; layers that do not (3 x 64 KB for 4x128) stream
+//     through a two-slot LDS ring filled by LDS-DMA (global_load_lds_dwordx4) one layer ahead, so
+//     the L2 -> LDS copy of layer l+1 overlaps the MFMAs of layer l.  One workgroup barrier per
+//     streamed layer.
+#pragma once
+#include "ac_dynamics.hpp"
+
+namespace ac {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MlpPlan {
+    int n_layers;
+    int KT[AC_MAX_LAYERS];       // ceil(n_in / 16)
+    int NT[AC_MAX_LAYERS];       // ceil(n_out / 16)
+    int act[AC_MAX_LAYERS];      // 0 identity, 1 tanh
+    int g_off[AC_MAX_LAYERS];    // float offset of the packed layer block in the global blob
+    int bytes[AC_MAX_LAYERS];    // block size: NT*KT*1024 (weights) + 1024 (bias piece)
+    int lds_off[AC_MAX_LAYERS];  // byte offset if resident, -1 if streamed through the ring
+    int ring_off[2];             // byte offsets of the two ring slots
+    int n_streamed;              // number of streamed layers per forward pass
+    int first_streamed;          // index of the first streamed layer (-1 if none)
+    int lds_total;               // dynamic LDS bytes to request
+};
+
+// ---- 16x16x4 fp32 matrix-multiply-accumulate on one wave -------------------------------------
+template <bool USE_MFMA> AC_DI f32x4 mma_16x16x4(float a, float b, f32x4 c) {
+    if constexpr (USE_MFMA) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    } else {
+        // "MFMA off" validation path: the same contraction with cross-lane reads on the VALU.
+        // A[i][k] lives on lane i + 16k, B[k][j] on lane j + 16k; this lane owns D[4g + r][col].
+        // k ascending with one fmaf per product = the MFMA's documented k-ordered fmaf chain.
+        const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float bk = __shfl(b, col + 16 * k, 64);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] = fmaf(__shfl(a, 4 * g + r + 16 * k, 64), bk, c[r]);
+        }
+        return c;
+    }
+}
+
+AC_DI float act_tanh(float x) { return tanhf(x); }
+
+// Copy `bytes` (a multiple of 1024: the host pads every layer block to whole pieces) from global to
+// LDS with LDS-DMA.  Every wave of the workgroup takes 1-KiB pieces round-robin; a piece is one
+// global_load_lds_dwordx4 wave-instruction (LDS destination = piece base + 16 * lane, all lanes active).
+AC_DI void lds_dma_copy(const float* __restrict__ gsrc, char* lds_dst, int bytes, int wave, int nwaves,
+                        int lane) {
+    const int pieces = bytes >> 10;
+    for (int p = wave; p < pieces; p += nwaves) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)((const char*)gsrc + (p << 10) + lane * 16),
+            (__attribute__((address_space(3))) void*)(lds_dst + (p << 10)), 16, 0, 0);
+    }
+}
+
+// NSLAB: 1 (values only) or 6 (value + 5 input tangents).  WT: register tiles per slab = max width / 16.
+template <int NSLAB, int WT, bool USE_MFMA>
+struct MlpEngine {
+    static constexpr bool kTangent = NSLAB > 1;
+    static constexpr int CH = WT < 4 ? WT : 4;  // output tiles computed together (independent accumulators)
+
+    float a[NSLAB][WT][4];
+    const MlpPlan& plan;
+    const float* __restrict__ gblob;
+    char* lds;
+    int lane, g, wave, nwaves;
+    int ring_pos;  // number of streamed layers consumed so far (slot = ring_pos & 1)
+
+    AC_DI MlpEngine(const MlpPlan& pl, const float* blob, char* lds_base)
+        : plan(pl), gblob(blob), lds(lds_base), ring_pos(0) {
+        lane = threadIdx.x & 63; g = lane >> 4; wave = threadIdx.x >> 6; nwaves = blockDim.x >> 6;
+    }
+
+    AC_DI int streamed_layer(int idx) const {  // idx-th streamed layer of the cyclic sequence
+        int seen = 0;
+        for (int l = 0; l < plan.n_layers; ++l)
+            if (plan.lds_off[l] < 0) { if (seen == idx) return l; ++seen; }
+        return -1;
+    }
+
+    // Prologue: resident layers + the first streamed layer into ring slot 0.
+    AC_DI void load_weights() {
+        for (int l = 0; l < plan.n_layers; ++l)
+            if (plan.lds_off[l] >= 0) lds_dma_copy(gblob + plan.g_off[l], lds + plan.lds_off[l], plan.bytes[l], wave, nwaves, lane);
+        if (plan.n_streamed > 0) {
+            const int l = plan.first_streamed;
+            lds_dma_copy(gblob + plan.g_off[l], lds + plan.ring_off[0], plan.bytes[l], wave, nwaves, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // drains vmcnt (LDS-DMA) and makes the image visible to every wave
+    }
+
+    // Must run before the wave exits: an LDS-DMA prefetch may still be in flight.
+    AC_DI void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+    // CNT output tiles (independent accumulators) x KT k-tiles for slab s; straight-line code, the next
+    // k-tile's A fragments are fetched (ds_read_b128) while the current one's MFMAs issue.
+    template <int CNT, int KT, int NT>
+    AC_DI void gemm_chunk(const f32x4* __restrict__ wf, const f32x4* __restrict__ bias4, int s, int nc, f32x4 (&o)[NT],
+                          const float (&in)[WT][4]) {
+        // The chunks of a layer are mutually independent; without a fence the machine scheduler interleaves
+        // them across the whole straight-line layer and the live accumulators no longer fit the register file.
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[CNT];
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+            if (s == 0) acc[i] = bias4[(nc + i) * 4 + g];  // value slab starts from the bias
+            else acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 wcur[CNT], wnext[CNT];
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) wcur[i] = wf[((nc + i) * KT + 0) * 64];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + 1 < KT) {
+#pragma unroll
+                for (int i = 0; i < CNT; ++i) wnext[i] = wf[((nc + i) * KT + kt + 1) * 64];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < CNT; ++i) acc[i] = mma_16x16x4<USE_MFMA>(wcur[i][r], in[kt][r], acc[i]);
+            if (kt + 1 < KT) {
+#pragma unroll
+                for (int i = 0; i < CNT; ++i) wcur[i] = wnext[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) o[nc + i] = acc[i];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // One Linear(+tanh) layer of static shape KT x NT tiles on all slabs.  wl: LDS address of the packed block.
+    // The host pads every hidden width to 16*WT, so only the shapes <1,WT> (first), <WT,WT> (hidden),
+    // <WT,1> (last) and <1,1> (single-layer net) occur.
+    template <int KT, int NT>
+    AC_DI void layer(const char* wl, int act) {
+        const f32x4* wf = reinterpret_cast<const f32x4*>(wl) + lane;
+        const f32x4* bias4 = reinterpret_cast<const f32x4*>(wl + NT * KT * 1024);
+        constexpr int C = NT < CH ? NT : CH;
+        static_assert(NT % C == 0, "tile count must be a multiple of the chunk");
+#pragma unroll
+        for (int s = 0; s < NSLAB; ++s) {
+            f32x4 o[NT];
+#pragma unroll
+            for (int nc = 0; nc < NT; nc += C) gemm_chunk<C, KT, NT>(wf, bias4, s, nc, o, a[s]);
+            // epilogue: activation on the value slab, act'(h) scaling on tangent slabs
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (s == 0) {
+                        a[0][nt][r] = act ? act_tanh(o[nt][r]) : o[nt][r];
+                    } else {
+                        const float h = a[0][nt][r];  // already the NEW value activation
+                        a[s][nt][r] = act ? o[nt][r] * fmaf(-h, h, 1.0f) : o[nt][r];
+                    }
+                }
+            }
+        }
+    }
+
+    // LDS address of layer l's block; for a streamed layer: wait for its DMA, then (the barrier having
+    // proven every wave is done with the other slot) request the next streamed layer into that slot.
+    AC_DI const char* acquire(int l) {
+        if (plan.lds_off[l] >= 0) return lds + plan.lds_off[l];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* wl = lds + plan.ring_off[ring_pos & 1];
+        const int nl = streamed_layer((ring_pos + 1) % plan.n_streamed);
+        lds_dma_copy(gblob + plan.g_off[nl], lds + plan.ring_off[(ring_pos + 1) & 1], plan.bytes[nl], wave, nwaves,
+                     lane);
+        ++ring_pos;
+        return wl;
+    }
+
+    // y[6] (and J[6][5] = dy/dz in tangent mode) of the raw network for normalised inputs z[5].
+    // Every lane of a unit passes the same z and receives the same outputs.  Wave-collective and,
+    // when layers are streamed, workgroup-collective (one barrier per streamed layer).
+    AC_DI void forward(const float z[5], float y[6], float (*J)[5]) {
+        // layer-0 input slab: rows 0..4 = z, rest 0 ; tangent slab j = unit vector e_j
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v = (row == k) ? z[k] : v;
+            a[0][0][r] = v;
+            if constexpr (kTangent) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) a[1 + j][0][r] = (row == j) ? 1.f : 0.f;
+            }
+        }
+        const int L = plan.n_layers;
+        if (L == 1) {
+            layer<1, 1>(acquire(0), plan.act[0]);
+        } else {
+            layer<1, WT>(acquire(0), plan.act[0]);
+#pragma nounroll
+            for (int l = 1; l < L - 1; ++l) layer<WT, WT>(acquire(l), plan.act[l]);
+            layer<WT, 1>(acquire(L - 1), plan.act[L - 1]);
+        }
+        // outputs: rows 0..5 of tile 0 — row k sits in register k&3 of lane (col, k>>2)
+        const int col = lane & 15;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int src = col + 16 * (k >> 2);
+            y[k] = __shfl(a[0][0][k & 3], src, 64);
+            if constexpr (kTangent) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) J[k][j] = __shfl(a[1 + j][0][k & 3], src, 64);
+            }
+        }
+    }
+};
+
+// Coefficient provider that plugs the engine into state_derivative().  prefetch() runs the network on the
+// primal aerodynamic inputs of the stage state and keeps only y[6] (+ J[6][5]); operator() then applies the
+// output scaler and, for duals, the chain rule  dC = J . d(inputs)  — the custom-Jacobian rule l4casadi
+// supplies to CasADi in the reference (coefficient_models.py:93-100).
+template <class Engine> struct MlpCoeffs {
+    Engine& eng;
+    float y[6];
+    float J[Engine::kTangent ? 6 : 1][5];
+    AC_DI explicit MlpCoeffs(Engine& e) : eng(e) {}
+
+    template <class T> AC_DI void prefetch(const DevParams& P, const T x[13], const float uv[7]) {
+        float xf[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) xf[i] = value_of(x[i]);
+        AeroPre<float> a;
+        aero_pre(P, xf, a);
+        const float in[5] = {a.qbar, a.alpha, a.beta, uv[0], uv[1]};
+        float z[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) z[j] = (in[j] - P.mlp_in_mean[j]) / P.mlp_in_std[j];
+        eng.forward(z, y, Engine::kTangent ? J : nullptr);
+    }
+
+    AC_DI void operator()(const DevParams& P, const AeroPre<float>& a, const float x[13], const float u[7],
+                          float C[6]) const {
+        (void)a; (void)x;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) C[k] = fmaf(y[k], P.mlp_out_std[k], P.mlp_out_mean[k]);
+        C[5] += (-0.1f * 6.0f * kDeg) * u[2];
+    }
+
+    template <int N>
+    AC_DI void operator()(const DevParams& P, const AeroPre<Dual<N>>& a, const Dual<N> x[13], const Dual<N> u[7],
+                          Dual<N> C[6]) const {
+        (void)x;
+        static_assert(Engine::kTangent, "dual coefficients need the tangent engine");
+        const Dual<N> in[5] = {a.qbar, a.alpha, a.beta, u[0], u[1]};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            C[k].v = fmaf(y[k], P.mlp_out_std[k], P.mlp_out_mean[k]);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) s = fmaf(J[k][j] * (P.mlp_out_std[k] / P.mlp_in_std[j]), in[j].d[i], s);
+                C[k].d[i] = s;
+            }
+        }
+        C[5] = C[5] + (-0.1f * 6.0f * kDeg) * u[2];
+    }
+};
+
+}  // namespace ac

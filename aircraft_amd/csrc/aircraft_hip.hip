@@ -1,0 +1,443 @@
+// aircraft_hip.hip — C ABI (include/aircraft_hip.h) + kernel dispatch for libaircraft_hip.so.
+// gfx950 only.  No allocation or synchronisation inside the compute entry points (graph-capturable).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ac_kernels_analytic.hpp"
+#include "ac_nn_decl.hpp"
+
+using namespace ac;
+
+namespace ac {
+// Trajectory cost for the random-restart driver: X [H+1][13][B] -> cost [B]
+__global__ __launch_bounds__(kBlock) void k_traj_cost(const float* __restrict__ X, long B, long H, float gx, float gy,
+                                                      float gz, float w_track, float w_goal,
+                                                      float* __restrict__ cost) {
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B) return;
+    float acc = 0.f, last = 0.f;
+    for (long k = 0; k <= H; ++k) {
+        const float* xk = X + k * 13 * B;
+        const float dx = xk[i] - gx, dy = xk[B + i] - gy, dz = xk[2 * B + i] - gz;
+        last = dx * dx + dy * dy + dz * dz;
+        acc += last;
+    }
+    cost[i] = w_track * acc + w_goal * last;
+}
+
+}  // namespace ac
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int hip_fail(hipError_t e, const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return AC_ERR_HIP;
+}
+#define AC_HIP(call)                                           \
+    do {                                                       \
+        hipError_t e_ = (call);                                \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);      \
+    } while (0)
+
+constexpr int kLdsBudget = 160 * 1024;  // gfx950 LDS per workgroup
+
+}  // namespace
+
+struct ac_handle {
+    DevParams dp;
+    int device;
+    bool has_linear, has_poly, has_mlp;
+    MlpPlan plan;
+    int wt;         // register tiles per slab the plan needs (2, 4 or 8)
+    int use_mfma;
+    float* d_blob;  // packed MLP weights + biases (device)
+    size_t blob_floats;
+    // last launch (profiling aid)
+    char last_name[64];
+    int last_grid, last_block, last_lds;
+};
+
+namespace {
+
+void note_launch(ac_handle* h, const char* name, int grid, int block, int lds) {
+    snprintf(h->last_name, sizeof(h->last_name), "%s", name);
+    h->last_grid = grid; h->last_block = block; h->last_lds = lds;
+}
+
+int check_params(const ac_params* p) {
+    if (!p) return AC_ERR_BAD_ARG;
+    if (p->substeps < 1) return AC_ERR_BAD_ARG;
+    if (p->model_kind < AC_MODEL_DEFAULT || p->model_kind > AC_MODEL_POLY) return AC_ERR_BAD_ARG;
+    return AC_OK;
+}
+
+int model_ready(const ac_handle* h) {
+    switch (h->dp.p.model_kind) {
+        case AC_MODEL_LINEAR: return h->has_linear ? AC_OK : AC_ERR_NO_MODEL;
+        case AC_MODEL_POLY: return h->has_poly ? AC_OK : AC_ERR_NO_MODEL;
+        case AC_MODEL_NN: return h->has_mlp ? AC_OK : AC_ERR_NO_MODEL;
+        default: return AC_OK;
+    }
+}
+
+template <class K> int set_lds_limit(K kernel, int bytes) {
+    if (bytes > 64 * 1024) AC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return AC_OK;
+}
+
+// ---- dispatch helpers --------------------------------------------------------------------------
+#define AC_LAUNCH_ANALYTIC(KERNEL, GRID, BLOCK, ...)                                                        \
+    do {                                                                                                    \
+        switch (h->dp.p.model_kind) {                                                                       \
+            case AC_MODEL_LINEAR: hipLaunchKernelGGL(KERNEL<AC_MODEL_LINEAR>, GRID, BLOCK, 0, st, h->dp, __VA_ARGS__); break; \
+            case AC_MODEL_POLY: hipLaunchKernelGGL(KERNEL<AC_MODEL_POLY>, GRID, BLOCK, 0, st, h->dp, __VA_ARGS__); break;     \
+            default: hipLaunchKernelGGL(KERNEL<AC_MODEL_DEFAULT>, GRID, BLOCK, 0, st, h->dp, __VA_ARGS__); break;             \
+        }                                                                                                   \
+    } while (0)
+
+// Instantiate an NN kernel template for the (WT, MFMA) the handle needs.
+#define AC_NN_CASE(WT_, MF_, KERNEL_EXPR, GRID, BLOCK, ...)                                          \
+    if (h->wt == WT_ && (h->use_mfma != 0) == MF_) {                                                 \
+        auto kern = KERNEL_EXPR;                                                                     \
+        int rc_ = set_lds_limit(kern, h->plan.lds_total);                                            \
+        if (rc_ != AC_OK) return rc_;                                                                \
+        hipLaunchKernelGGL(kern, GRID, BLOCK, h->plan.lds_total, st, h->dp, h->plan, h->d_blob, __VA_ARGS__); \
+        launched = true;                                                                             \
+    }
+
+}  // namespace
+
+extern "C" {
+
+const char* ac_last_error(void) { return g_err; }
+const char* ac_version(void) { return "aircraft_hip 0.1 (gfx950)"; }
+
+int ac_device_arch(char* buf, size_t len) {
+    if (!buf || len == 0) return AC_ERR_BAD_ARG;
+    int dev = 0;
+    AC_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    AC_HIP(hipGetDeviceProperties(&prop, dev));
+    snprintf(buf, len, "%s", prop.gcnArchName);
+    return AC_OK;
+}
+
+int ac_create(const ac_params* params, ac_handle** out) {
+    if (!out) return AC_ERR_BAD_ARG;
+    int rc = check_params(params);
+    if (rc != AC_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        snprintf(g_err, sizeof(g_err), "no HIP device visible");
+        return AC_ERR_NO_DEVICE;
+    }
+    ac_handle* h = new (std::nothrow) ac_handle();
+    if (!h) return AC_ERR_BAD_ARG;
+    memset(h, 0, sizeof(*h));
+    h->dp.p = *params;
+    AC_HIP(hipGetDevice(&h->device));
+    *out = h;
+    return AC_OK;
+}
+
+int ac_destroy(ac_handle* h) {
+    if (!h) return AC_ERR_BAD_ARG;
+    if (h->d_blob) (void)hipFree(h->d_blob);
+    delete h;
+    return AC_OK;
+}
+
+int ac_set_params(ac_handle* h, const ac_params* params) {
+    if (!h) return AC_ERR_BAD_ARG;
+    int rc = check_params(params);
+    if (rc != AC_OK) return rc;
+    h->dp.p = *params;
+    return AC_OK;
+}
+
+int ac_set_linear(ac_handle* h, const float* W) {
+    if (!h || !W) return AC_ERR_BAD_ARG;
+    memcpy(h->dp.linear_W, W, sizeof(float) * 36);
+    h->has_linear = true;
+    return AC_OK;
+}
+
+int ac_set_poly(ac_handle* h, const float* coef, const float* intercept) {
+    if (!h || !coef || !intercept) return AC_ERR_BAD_ARG;
+    memcpy(h->dp.poly_coef, coef, sizeof(float) * 6 * 34);
+    memcpy(h->dp.poly_intercept, intercept, sizeof(float) * 6);
+    h->has_poly = true;
+    return AC_OK;
+}
+
+int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, const float* const* W,
+               const float* const* b, const float* in_mean, const float* in_std, const float* out_mean,
+               const float* out_std, int use_mfma) {
+    if (!h || !widths || !act || !W || !b || !in_mean || !in_std || !out_mean || !out_std) return AC_ERR_BAD_ARG;
+    if (n_layers < 1 || n_layers > AC_MAX_LAYERS) return AC_ERR_BAD_ARG;
+    if (widths[0] != 5 || widths[n_layers] != 6) return AC_ERR_BAD_ARG;
+    for (int l = 0; l <= n_layers; ++l) {
+        if (widths[l] < 1) return AC_ERR_BAD_ARG;
+        if (widths[l] > AC_MAX_WIDTH) {
+            snprintf(g_err, sizeof(g_err), "MLP width %d > AC_MAX_WIDTH %d", widths[l], AC_MAX_WIDTH);
+            return AC_ERR_UNSUPPORTED;
+        }
+    }
+    MlpPlan pl;
+    memset(&pl, 0, sizeof(pl));
+    pl.n_layers = n_layers;
+    // Hidden widths are zero-padded to one common multiple of 16 (wt tiles): padded neurons get zero weights
+    // and zero bias, so they output act(0) = 0 and feed nothing forward.  Input (5) pads to one tile, output (6)
+    // to one tile.  The engine then only meets the static shapes <1,wt>, <wt,wt>, <wt,1>, <1,1>.
+    int maxh = 0;
+    for (int l = 1; l < n_layers; ++l) maxh = std::max(maxh, widths[l]);
+    const int maxt = (maxh + 15) / 16;
+    const int wt = maxt <= 2 ? 2 : (maxt <= 4 ? 4 : 8);
+    size_t total_floats = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (!W[l] || !b[l]) return AC_ERR_BAD_ARG;
+        pl.KT[l] = (l == 0) ? 1 : wt;
+        pl.NT[l] = (l == n_layers - 1) ? 1 : wt;
+        pl.act[l] = act[l] ? 1 : 0;
+        pl.bytes[l] = pl.NT[l] * pl.KT[l] * 1024 + 1024;  // weights + one 1-KiB bias piece (whole LDS-DMA pieces only)
+        pl.g_off[l] = (int)total_floats;
+        total_floats += (size_t)pl.bytes[l] / 4;
+    }
+    // Pack: [nt][kt][lane][4] with lane = col + 16 g -> W[16 nt + col][16 kt + 4 g + j]; then the padded bias.
+    std::vector<float> blob(total_floats, 0.f);
+    for (int l = 0; l < n_layers; ++l) {
+        const int nin = widths[l], nout = widths[l + 1], KT = pl.KT[l], NT = pl.NT[l];
+        float* dst = blob.data() + pl.g_off[l];
+        for (int nt = 0; nt < NT; ++nt)
+            for (int kt = 0; kt < KT; ++kt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = 16 * nt + (lane & 15), k = 16 * kt + 4 * (lane >> 4) + j;
+                        dst[((size_t)(nt * KT + kt) * 64 + lane) * 4 + j] =
+                            (row < nout && k < nin) ? W[l][(size_t)row * nin + k] : 0.f;
+                    }
+        float* bd = dst + (size_t)NT * KT * 256;
+        for (int i = 0; i < NT * 16; ++i) bd[i] = i < nout ? b[l][i] : 0.f;
+    }
+    // LDS plan: everything resident if it fits; otherwise the largest layers stream through a 2-slot ring.
+    {
+        int total = 0;
+        for (int l = 0; l < n_layers; ++l) total += pl.bytes[l];
+        for (int l = 0; l < n_layers; ++l) pl.lds_off[l] = 0;
+        if (total <= kLdsBudget) {
+            int off = 0;
+            for (int l = 0; l < n_layers; ++l) { pl.lds_off[l] = off; off += pl.bytes[l]; }
+            pl.n_streamed = 0; pl.first_streamed = -1; pl.lds_total = off;
+        } else {
+            int big = 0;
+            for (int l = 0; l < n_layers; ++l) big = std::max(big, pl.bytes[l]);
+            // stream every layer of the maximal size class; keep the rest resident
+            int off = 0, resident = 0;
+            for (int l = 0; l < n_layers; ++l) if (pl.bytes[l] < big) resident += pl.bytes[l];
+            if (resident + 2 * big > kLdsBudget) {
+                snprintf(g_err, sizeof(g_err), "MLP does not fit the LDS plan (%d resident + 2 x %d ring)", resident, big);
+                return AC_ERR_UNSUPPORTED;
+            }
+            pl.first_streamed = -1;
+            for (int l = 0; l < n_layers; ++l) {
+                if (pl.bytes[l] < big) { pl.lds_off[l] = off; off += pl.bytes[l]; }
+                else { pl.lds_off[l] = -1; pl.n_streamed++; if (pl.first_streamed < 0) pl.first_streamed = l; }
+            }
+            pl.ring_off[0] = off; pl.ring_off[1] = off + big;
+            pl.lds_total = off + 2 * big;
+        }
+    }
+    float* d = nullptr;
+    AC_HIP(hipMalloc(&d, total_floats * sizeof(float)));
+    hipError_t e = hipMemcpy(d, blob.data(), total_floats * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "hipMemcpy(mlp blob)"); }
+    if (h->d_blob) (void)hipFree(h->d_blob);
+    h->d_blob = d;
+    h->blob_floats = total_floats;
+    h->plan = pl;
+    h->wt = wt;
+    h->use_mfma = use_mfma ? 1 : 0;
+    memcpy(h->dp.mlp_in_mean, in_mean, 5 * sizeof(float));
+    memcpy(h->dp.mlp_in_std, in_std, 5 * sizeof(float));
+    memcpy(h->dp.mlp_out_mean, out_mean, 6 * sizeof(float));
+    memcpy(h->dp.mlp_out_std, out_std, 6 * sizeof(float));
+    h->has_mlp = true;
+    return AC_OK;
+}
+
+// ---- compute entry points ------------------------------------------------------------------------
+static int launch_nn_fwd(ac_handle* h, int op, const float* X, const float* U, float dt, const float* dtp, long n,
+                         long blk, float* out, hipStream_t st) {
+    const int grid = (int)((n + 63) / 64);
+    bool launched = false;
+#define AC_FWD_OPS(WT_, MF_)                                                                                   \
+    if (op == OP_DERIV) { AC_NN_CASE(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_DERIV>), grid, kBlock, X, U, dt, dtp, n, blk, out) } \
+    else if (op == OP_STEP) { AC_NN_CASE(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_STEP>), grid, kBlock, X, U, dt, dtp, n, blk, out) } \
+    else { AC_NN_CASE(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_AERO>), grid, kBlock, X, U, dt, dtp, n, blk, out) }
+    AC_FWD_OPS(2, true) AC_FWD_OPS(4, true) AC_FWD_OPS(8, true)
+    AC_FWD_OPS(2, false) AC_FWD_OPS(4, false) AC_FWD_OPS(8, false)
+#undef AC_FWD_OPS
+    if (!launched) return AC_ERR_UNSUPPORTED;
+    note_launch(h, op == OP_DERIV ? "k_nn_fwd<deriv>" : (op == OP_STEP ? "k_nn_fwd<step>" : "k_nn_fwd<aero>"), grid,
+                kBlock, h->plan.lds_total);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_state_derivative_f32(ac_handle* h, const float* X, const float* U, long n, float* Xdot, void* stream) {
+    const long blk = n;
+    if (h && n == 0) return AC_OK;  // empty batch: nothing to do (pointers may be NULL)
+    if (!h || !X || !U || !Xdot || n < 0) return AC_ERR_BAD_ARG;
+    int rc = model_ready(h);
+    if (rc != AC_OK) return rc;
+    if (n == 0) return AC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (h->dp.p.model_kind == AC_MODEL_NN) return launch_nn_fwd(h, OP_DERIV, X, U, 0.f, nullptr, n, blk, Xdot, st);
+    const int grid = (int)((n + kBlock - 1) / kBlock);
+    AC_LAUNCH_ANALYTIC(k_state_derivative, grid, kBlock, X, U, n, blk, Xdot);
+    note_launch(h, "k_state_derivative", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+static int step_impl(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long n, long blk,
+                     float* Xn, void* stream) {
+    if (h && n == 0) return AC_OK;
+    if (!h || !X || !U || !Xn || n < 0 || blk < 0) return AC_ERR_BAD_ARG;
+    int rc = model_ready(h);
+    if (rc != AC_OK) return rc;
+    if (n == 0) return AC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (h->dp.p.model_kind == AC_MODEL_NN) return launch_nn_fwd(h, OP_STEP, X, U, dt, dt_per_unit, n, blk, Xn, st);
+    const int grid = (int)((n + kBlock - 1) / kBlock);
+    AC_LAUNCH_ANALYTIC(k_step, grid, kBlock, X, U, dt, dt_per_unit, n, blk, Xn);
+    note_launch(h, "k_step", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_step_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long n, float* Xn,
+                void* stream) {
+    return step_impl(h, X, U, dt, dt_per_unit, n, n, Xn, stream);
+}
+
+int ac_shoot_step_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long B, long H,
+                      float* Xn, void* stream) {
+    if (B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    return step_impl(h, X, U, dt, dt_per_unit, B * H, B, Xn, stream);
+}
+
+int ac_aero_f32(ac_handle* h, const float* X, const float* U, long n, float* out, void* stream) {
+    const long blk = n;
+    if (h && n == 0) return AC_OK;
+    if (!h || !X || !U || !out || n < 0) return AC_ERR_BAD_ARG;
+    int rc = model_ready(h);
+    if (rc != AC_OK) return rc;
+    if (n == 0) return AC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (h->dp.p.model_kind == AC_MODEL_NN) return launch_nn_fwd(h, OP_AERO, X, U, 0.f, nullptr, n, blk, out, st);
+    const int grid = (int)((n + kBlock - 1) / kBlock);
+    AC_LAUNCH_ANALYTIC(k_aero, grid, kBlock, X, U, n, blk, out);
+    note_launch(h, "k_aero", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_rollout_f32(ac_handle* h, const float* X0, const float* U, float dt, long B, long H, float* Xout,
+                   void* stream) {
+    if (h && B == 0) return AC_OK;
+    if (!h || !X0 || !Xout || B < 0 || H < 0 || (H > 0 && !U)) return AC_ERR_BAD_ARG;
+    int rc = model_ready(h);
+    if (rc != AC_OK) return rc;
+    if (B == 0) return AC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (h->dp.p.model_kind == AC_MODEL_NN) {
+        const int grid = (int)((B + 15) / 16);
+        bool launched = false;
+        AC_NN_CASE(2, true, (k_nn_rollout<2, true>), grid, 64, X0, U, dt, B, H, Xout)
+        AC_NN_CASE(4, true, (k_nn_rollout<4, true>), grid, 64, X0, U, dt, B, H, Xout)
+        AC_NN_CASE(8, true, (k_nn_rollout<8, true>), grid, 64, X0, U, dt, B, H, Xout)
+        AC_NN_CASE(2, false, (k_nn_rollout<2, false>), grid, 64, X0, U, dt, B, H, Xout)
+        AC_NN_CASE(4, false, (k_nn_rollout<4, false>), grid, 64, X0, U, dt, B, H, Xout)
+        AC_NN_CASE(8, false, (k_nn_rollout<8, false>), grid, 64, X0, U, dt, B, H, Xout)
+        if (!launched) return AC_ERR_UNSUPPORTED;
+        note_launch(h, "k_nn_rollout", grid, 64, h->plan.lds_total);
+        AC_HIP(hipGetLastError());
+        return AC_OK;
+    }
+    const int grid = (int)((B + 63) / 64);
+    AC_LAUNCH_ANALYTIC(k_rollout, grid, 64, X0, U, dt, B, H, Xout);
+    note_launch(h, "k_rollout", grid, 64, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long n, long blk,
+                     float* Xn, float* A, float* Bm, float* c, void* stream) {
+    if (h && n == 0) return AC_OK;
+    if (!h || !X || !U || !Xn || !A || !Bm || n < 0 || blk < 0) return AC_ERR_BAD_ARG;
+    int rc = model_ready(h);
+    if (rc != AC_OK) return rc;
+    if (n == 0) return AC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)((n + 63) / 64);  // 16 units per wave, 4 waves per workgroup
+    if (h->dp.p.model_kind == AC_MODEL_NN) {
+        bool launched = false;
+        AC_NN_CASE(2, true, (k_nn_step_sens<2, true>), grid, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c)
+        AC_NN_CASE(4, true, (k_nn_step_sens<4, true>), grid, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c)
+        AC_NN_CASE(8, true, (k_nn_step_sens<8, true>), grid, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c)
+        AC_NN_CASE(2, false, (k_nn_step_sens<2, false>), grid, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c)
+        AC_NN_CASE(4, false, (k_nn_step_sens<4, false>), grid, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c)
+        AC_NN_CASE(8, false, (k_nn_step_sens<8, false>), grid, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c)
+        if (!launched) return AC_ERR_UNSUPPORTED;
+        note_launch(h, "k_nn_step_sens", grid, kBlock, h->plan.lds_total);
+        AC_HIP(hipGetLastError());
+        return AC_OK;
+    }
+    AC_LAUNCH_ANALYTIC(k_step_sens, grid, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c);
+    note_launch(h, "k_step_sens", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_step_sens_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long n,
+                     float* Xn, float* A, float* Bm, float* c, void* stream) {
+    return sens_impl(h, X, U, dt, dt_per_unit, n, n, Xn, A, Bm, c, stream);
+}
+
+int ac_shoot_sens_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long B, long H,
+                      float* Xn, float* A, float* Bm, float* c, void* stream) {
+    if (B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    return sens_impl(h, X, U, dt, dt_per_unit, B * H, B, Xn, A, Bm, c, stream);
+}
+
+int ac_traj_cost_f32(ac_handle* h, const float* X, long B, long H, const float* goal3, float w_track, float w_goal,
+                     float* cost, void* stream) {
+    if (h && B == 0) return AC_OK;
+    if (!h || !X || !goal3 || !cost || B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)((B + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_traj_cost, grid, kBlock, 0, st, X, B, H, goal3[0], goal3[1], goal3[2], w_track, w_goal, cost);
+    note_launch(h, "k_traj_cost", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_last_launch(const ac_handle* h, char* name, size_t len, int* grid, int* block, int* lds_bytes) {
+    if (!h) return AC_ERR_BAD_ARG;
+    if (name && len) snprintf(name, len, "%s", h->last_name);
+    if (grid) *grid = h->last_grid;
+    if (block) *block = h->last_block;
+    if (lds_bytes) *lds_bytes = h->last_lds;
+    return AC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+/*
+ * aircraft_hip.h — C ABI of libaircraft_hip.so: the MI355X (gfx950) implementation of the
+ * AIrcraft MPC-rollout hot path (6-DoF RK4 step through an aerodynamic-coefficient model,
+ * plus first-order step sensitivities).
+ *
+ * Boundary: these entry points replace the CasADi `ca.Function` objects that the reference's
+ * control layer consumes — `system.state_update` / `system.state_derivative`
+ * (reference: src/aircraft/control/base.py:187-190) — and the `ca.jacobian` of them
+ * (control/aircraft.py:85-95, control/base.py:279-280, 314-315).  A reference-side binding is a
+ * ctypes stub; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - state  x = [p_ned(3), v_ned(3), q_frd_ned(4, xyzw), omega_frd(3)]   (dynamics/base.py:84-106)
+ *   - control u = [aileron, elevator, rudder (deg), thrust(3), flaps]       (dynamics/aircraft.py:143-166)
+ *   - batched arrays are component-major float32 DEVICE buffers: X is [13][n], U is [7][n] — the
+ *     reference's own column-mapped call convention (`(13,N)` matrices, main/control/control.py:63),
+ *     which is also the coalesced layout on the GPU.  A "unit" is one (x_k, u_k) pair: one MPC
+ *     instance at one shooting node.
+ *   - the caller owns every buffer; the library never allocates outputs.  The handle owns device
+ *     copies of the coefficient-model data.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ *     does no allocation and no synchronisation, and is therefore hipGraph-capturable.
+ *   - return value: AC_OK (0) or a negative ac_status; nothing is thrown across the ABI.  NaNs in the
+ *     inputs propagate to the outputs unchanged (the reference's callers test np.isnan,
+ *     main/dynamics/dynamics.py:108).
+ *   - thread-compatible per handle: no global mutable state.
+ */
+#ifndef AIRCRAFT_HIP_H
+#define AIRCRAFT_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AC_NUM_STATES 13   /* SixDOF.num_states,   dynamics/base.py:101 */
+#define AC_NUM_CONTROLS 7  /* Aircraft.num_controls, dynamics/aircraft.py:162 */
+#define AC_AERO_ROWS 20
+#define AC_MAX_LAYERS 8
+#define AC_MAX_WIDTH 128   /* widest MLP layer the register-resident MFMA engine supports */
+
+typedef enum ac_status {
+    AC_OK = 0,
+    AC_ERR_BAD_ARG = -1,       /* NULL pointer, negative size, unknown enum */
+    AC_ERR_HIP = -2,           /* a HIP runtime call failed; see ac_last_error() */
+    AC_ERR_UNSUPPORTED = -3,   /* e.g. MLP wider than AC_MAX_WIDTH */
+    AC_ERR_NO_MODEL = -4,      /* model_kind needs data that was never set */
+    AC_ERR_NO_DEVICE = -5      /* no gfx950 device visible */
+} ac_status;
+
+/* Registry keys of COEFF_MODEL_REGISTRY, dynamics/coefficient_models.py:32-37 */
+typedef enum ac_model_kind { AC_MODEL_DEFAULT = 0, AC_MODEL_LINEAR = 1, AC_MODEL_NN = 2, AC_MODEL_POLY = 3 } ac_model_kind;
+
+/* Constants of one airframe + integration options.
+ * Mirrors AircraftOpts / SixDOFOpts / AircraftConfiguration
+ * (dynamics/aircraft.py:22-38, dynamics/base.py:9-14, utils.py:201-215).
+ * inertia / inertia_inv are computed by the host in float64 from Ixx..Ixz, mass and com
+ * (dynamics/aircraft.py:168-187, dynamics/base.py:139-144) and rounded once. */
+typedef struct ac_params {
+    float mass, S, b, c;
+    float inertia[9];
+    float inertia_inv[9];
+    float com[3];
+    float rudder_moment_arm;
+    float epsilon;
+    float gravity[3];
+    int substeps;       /* physical_integration_substeps (>=1) */
+    int normalise;      /* SixDOF.normalise: q <- q/|q| once after the last sub-step */
+    int stall_scaling;  /* AircraftOpts.stall_scaling */
+    int model_kind;     /* ac_model_kind */
+} ac_params;
+
+typedef struct ac_handle ac_handle;
+
+/* Lifetime.  ac_create binds the handle to the CURRENT HIP device. */
+int ac_create(const ac_params* params, ac_handle** out);
+int ac_destroy(ac_handle* h);
+/* Replace the scalar parameters (e.g. after the driver overrides aircraft.com, control.py:172). */
+int ac_set_params(ac_handle* h, const ac_params* params);
+
+/* Coefficient-model data (HOST pointers; copied).
+ * linear: W[6][6] row-major, columns [qbar, alpha, beta, aileron, elevator, 1]   (coefficient_models.py:80-89)
+ * poly:   coef[6][34], intercept[6]; sklearn PolynomialFeatures(3) order over (alpha, beta, aileron, elevator)
+ *                                                                                 (coefficient_models.py:106-133)
+ * mlp:    n_layers Linear layers; W[l] is [widths[l+1]][widths[l]] row-major (torch layout); act[l] = 0 identity,
+ *         1 tanh after layer l; widths[0] must be 5, widths[n_layers] must be 6; input/output scalers as in
+ *         ScaledModel (surrogates/models.py:101-155).  use_mfma = 0 selects the VALU cross-lane matmul
+ *         ("MFMA off" validation baseline), 1 the v_mfma_f32_16x16x4_f32 path. */
+int ac_set_linear(ac_handle* h, const float* W);
+int ac_set_poly(ac_handle* h, const float* coef, const float* intercept);
+int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, const float* const* W,
+               const float* const* b, const float* in_mean, const float* in_std, const float* out_mean,
+               const float* out_std, int use_mfma);
+
+/* x_dot = f(x,u)                                   — SixDOF.state_derivative, dynamics/base.py:385-406 */
+int ac_state_derivative_f32(ac_handle* h, const float* X, const float* U, long n, float* Xdot, void* stream);
+
+/* x+ = F(x,u,dt): `substeps` RK4 steps of dt/substeps — SixDOF.state_update, dynamics/base.py:450-480.
+ * dt_per_unit: NULL -> every unit uses dt; else [n] per-unit step (dt_k = 1/progress_k^2, control/base.py:276). */
+int ac_step_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long n,
+                float* Xn, void* stream);
+
+/* Rollout X[k+1] = F(X[k], U[k], dt), k = 0..H-1    — Controller.initialise, main/control/control.py:72-93;
+ * MHTT.initialise, control/moving_horizon.py:203-213.
+ * X0 [13][B]; U [H][7][B]; Xout [H+1][13][B] with Xout[0] = X0. */
+int ac_rollout_f32(ac_handle* h, const float* X0, const float* U, float dt, long B, long H, float* Xout,
+                   void* stream);
+
+/* Step + first-order sensitivities (the multiple-shooting defect Jacobian blocks):
+ *   Xn [13][n], A = dF/dx [13][13][n], Bm = dF/du [13][7][n], c = dF/d(dt) [13][n] (c may be NULL)
+ *                                                   — ca.jacobian(state_update, .), control/aircraft.py:85-95 */
+int ac_step_sens_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long n,
+                     float* Xn, float* A, float* Bm, float* c, void* stream);
+
+/* Multiple-shooting forms: every (instance b, node k) pair of a trajectory is an independent unit
+ * (x_{k+1} - F(x_k, u_k, dt_k) = 0, control/base.py:275-286, built for k = 0..N-1 by setup(), :423-443).
+ * Buffers are rollout-shaped and used IN PLACE (no transpose): X [>=H][13][B] (nodes 0..H-1 are read),
+ * U [H][7][B], dt_per_unit NULL or [H][B]; outputs Xn [H][13][B] (= F(x_k,u_k): subtract from X[k+1] for the
+ * defect), A [H][13][13][B], Bm [H][13][7][B], c [H][13][B] (c may be NULL). */
+int ac_shoot_step_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long B,
+                      long H, float* Xn, void* stream);
+int ac_shoot_sens_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long B,
+                      long H, float* Xn, float* A, float* Bm, float* c, void* stream);
+
+/* Aerodynamic getters, out [20][n]: v_frd_rel(3), airspeed, alpha, beta, qbar, coefficients(6),
+ * forces_frd(3), moments_frd(3), 0                  — dynamics/base.py:147-278, dynamics/aircraft.py:255-330 */
+int ac_aero_f32(ac_handle* h, const float* X, const float* U, long n, float* out, void* stream);
+
+/* Trajectory cost + best-K selection used by the sharded random-restart driver (build-side).
+ * cost[b] = sum_k |p_k - goal|^2 * w_track  +  w_goal * |p_H - goal|^2 ; X is a rollout [H+1][13][B] (device),
+ * goal3 is a HOST pointer to 3 floats, cost [B] (device). */
+int ac_traj_cost_f32(ac_handle* h, const float* X, long B, long H, const float* goal3, float w_track, float w_goal,
+                     float* cost, void* stream);
+
+/* Diagnostics */
+const char* ac_last_error(void);     /* thread-local text of the last failing HIP call */
+const char* ac_version(void);
+int ac_device_arch(char* buf, size_t len);  /* gcnArchName of the current device */
+/* Name + launch geometry of the kernel the last call on this handle dispatched (for profiling). */
+int ac_last_launch(const ac_handle* h, char* name, size_t len, int* grid, int* block, int* lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

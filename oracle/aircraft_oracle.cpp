@@ -55,8 +55,8 @@ template <int N> inline Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) {
     Dual<N> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r;
 }
 template <int N> inline Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) {
-    Dual<N> r; const double inv = 1.0 / b.v; r.v = a.v * inv;
-    for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+    Dual<N> r; r.v = a.v / b.v;  // the value part is computed exactly as the plain-double path computes it
+    for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v;
     return r;
 }
 template <int N> inline Dual<N> operator+(const Dual<N>& a, double b) { Dual<N> r = a; r.v += b; return r; }
@@ -67,7 +67,9 @@ template <int N> inline Dual<N> operator*(const Dual<N>& a, double b) {
     Dual<N> r; r.v = a.v * b; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b; return r;
 }
 template <int N> inline Dual<N> operator*(double b, const Dual<N>& a) { return a * b; }
-template <int N> inline Dual<N> operator/(const Dual<N>& a, double b) { return a * (1.0 / b); }
+template <int N> inline Dual<N> operator/(const Dual<N>& a, double b) {
+    Dual<N> r; r.v = a.v / b; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] / b; return r;
+}
 template <int N> inline Dual<N> operator/(double a, const Dual<N>& b) { return Dual<N>(a) / b; }
 
 inline double value_of(double x) { return x; }

@@ -1,0 +1,156 @@
+"""CPU tests of the host layer: the C-ABI library loads and exports every declared symbol, the plugin surface
+mirrors the reference's, the model-data loaders work.  No compute call is made (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.helpers import GOLDEN, ROOT, golden, make_aircraft
+
+
+def test_library_exports_every_declared_symbol():
+    from aircraft_amd import _lib
+
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "aircraft_hip.h")).read()
+    declared = set(re.findall(r"\b(ac_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ac_handle", "ac_params"}
+    assert declared, "no prototypes parsed"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.ac_version().startswith(b"aircraft_hip")
+
+
+def test_struct_layout_matches_header():
+    from aircraft_amd import _lib
+
+    # 4 + 9 + 9 + 3 + 1 + 1 + 3 floats, 4 ints
+    assert ctypes.sizeof(_lib.AcParams) == (4 + 9 + 9 + 3 + 1 + 1 + 3) * 4 + 4 * 4
+
+
+def test_no_gpu_calls_fail_loudly():
+    """Without a GPU the product path raises; it never falls back to the oracle or any CPU code."""
+    import torch
+
+    from aircraft_amd import AircraftHipError
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ac = make_aircraft("default")
+    with pytest.raises(AircraftHipError):
+        ac.state_update(np.zeros((13, 4)), np.zeros((7, 4)), 0.01)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "aircraft_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "libaircraft_oracle" not in txt, f
+
+
+def test_plugin_surface_mirrors_reference():
+    from aircraft_amd import COEFF_MODEL_REGISTRY, Aircraft, AircraftConfiguration, AircraftOpts
+
+    assert set(COEFF_MODEL_REGISTRY) == {"linear", "poly", "nn", "default"}  # coefficient_models.py:32-37
+    opts = AircraftOpts(coeff_model_type="no-such-model", aircraft_config=AircraftConfiguration({"mass": 4.0}))
+    ac = Aircraft(opts)
+    assert ac.model_kind == "default"  # unknown key falls back silently (aircraft.py:37)
+    assert ac.mass == 4.0 and opts.mass == 4.0  # mass comes from the aircraft config (aircraft.py:34)
+    assert ac.num_states == 13 and ac.num_controls == 7
+    f = ac.state_update
+    assert (f.size1_in(0), f.size1_in(1), f.size1_in(2)) == (13, 7, 1)  # control/base.py:188-189
+    assert ac.state_derivative.size1_in(0) == 13
+    assert ac.physical_integration_substeps == 10 and ac.normalise is False  # dynamics/base.py:12, 33
+    for name in ("v_frd_rel", "airspeed", "alpha", "beta", "qbar", "coefficients", "forces_frd", "moments_frd",
+                 "phi", "theta", "psi"):
+        assert callable(getattr(ac, name))
+
+
+def test_inertia_tensor_with_com_shift():
+    ac = make_aircraft("default")
+    I = ac.inertia_tensor
+    x, y, z = ac.com
+    m = ac.mass
+    assert np.isclose(I[0, 0], 0.155 + m * (y * y + z * z))
+    assert np.isclose(I[0, 2], 0.01 - m * x * z) and np.isclose(I[2, 0], I[0, 2])
+    assert np.allclose(ac.inverse_inertia_tensor @ I, np.eye(3), atol=1e-12)
+    p = ac._param_struct()
+    assert np.allclose(np.array(p.inertia[:]).reshape(3, 3), I, rtol=1e-6)
+
+
+def test_param_struct_tracks_attribute_changes():
+    ac = make_aircraft("poly")
+    a = bytes(ac._param_struct())
+    ac.com = np.array([0.05, 0.0, 0.01]); ac.normalise = True; ac.physical_integration_substeps = 3
+    p = ac._param_struct()
+    assert bytes(p) != a and p.normalise == 1 and p.substeps == 3 and abs(p.com[0] - 0.05) < 1e-7
+
+
+def test_controller_sets_normalise_like_reference():
+    from aircraft_amd.control import MultipleShooting
+
+    ac = make_aircraft("poly")
+    ms = MultipleShooting(system=ac, dt=0.01, num_nodes=50, opts={"quaternion": "integration"})
+    assert ac.normalise is True and ms.state_dim == 13 and ms.control_dim == 7
+    MultipleShooting(system=ac, dt=0.01, num_nodes=50, opts={"quaternion": "constraint"})
+    assert ac.normalise is False
+    assert np.isclose(MultipleShooting.dt_from_progress(10.0), 0.01)  # dt = 1/progress^2
+
+
+def test_model_loaders(tmp_path):
+    from aircraft_amd import MlpData, load_linear, load_model, load_poly
+
+    coef, ic = load_poly(os.path.join(GOLDEN, "poly_coef.npz"))
+    assert coef.shape == (6, 34) and np.isclose(ic[0], -0.023165109898439548)
+    assert load_linear(os.path.join(GOLDEN, "linearised.npz")).shape == (6, 6)
+    csv = tmp_path / "lin.csv"
+    W = golden("linearised.npz")["W"]
+    csv.write_text("q,alpha,beta,aileron,elevator,intercept\n" + "\n".join(",".join(repr(float(v)) for v in r) for r in W))
+    assert np.array_equal(load_linear(str(csv)), W)
+    # a reference-format .pth checkpoint (keys of train_nn_surrogate.py:245-251) round-trips through load_model
+    import torch
+
+    w = golden("scaledmodel_weights.npz")
+    sd = {"core_layers.0.weight": torch.tensor(w["W0"]), "core_layers.0.bias": torch.tensor(w["b0"]),
+          "core_layers.1.weight": torch.tensor(w["W1"]), "core_layers.1.bias": torch.tensor(w["b1"]),
+          "core_layers.3.weight": torch.tensor(w["W2"]), "core_layers.3.bias": torch.tensor(w["b2"])}
+    ck = {"model_state_dict": sd, **{k: torch.tensor(w[k]) for k in ("input_mean", "input_std", "output_mean", "output_std")}}
+    pth = tmp_path / "m.pth"
+    torch.save(ck, pth)
+    m = load_model(str(pth))
+    assert m.widths == [5, 16, 32, 6] and m.act == [0, 1, 0] and m.flops_forward() == 1568
+    syn = MlpData.synthetic((128, 128, 128, 128))
+    assert syn.flops_forward() == 101120 and MlpData.synthetic((64, 64, 64)).flops_forward() == 17792
+    assert np.array_equal(syn.weights[0], MlpData.synthetic((128, 128, 128, 128)).weights[0])  # seeded
+
+
+def test_restricted_unpickler_blocks_code_execution(tmp_path):
+    import pickle
+
+    from aircraft_amd.utils import load_poly
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > /dev/null",))
+
+    p = tmp_path / "evil.pkl"
+    p.write_bytes(pickle.dumps({"fitted_models": Evil()}))
+    with pytest.raises(pickle.UnpicklingError):
+        load_poly(str(p))
+
+
+def test_synthetic_inputs_are_in_envelope_and_seeded():
+    from aircraft_amd.synthetic import synthetic_problem, synthetic_units
+
+    X, U = synthetic_units(500, seed=42)
+    X2, _ = synthetic_units(500, seed=42)
+    assert np.array_equal(X, X2)
+    assert np.abs(np.linalg.norm(X[6:10], axis=0) - 1).max() < 1e-12
+    V = np.linalg.norm(X[3:6], axis=0)
+    assert V.min() >= 30 and V.max() <= 80 and (X[2] < 0).all() and np.abs(U[:3]).max() <= 5
+    X0, Us = synthetic_problem(16, 50)
+    assert X0.shape == (13, 16) and Us.shape == (50, 7, 16) and not Us[:, 3:].any()
