@@ -39,25 +39,33 @@ struct MlpPlan {
 };
 
 // ---- 16x16x4 fp32 matrix-multiply-accumulate on one wave -------------------------------------
-template <bool USE_MFMA> AC_DI f32x4 mma_16x16x4(float a, float b, f32x4 c) {
-    if constexpr (USE_MFMA) {
-        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-    } else {
-        // "MFMA off" validation path: the same contraction with cross-lane reads on the VALU.
-        // A[i][k] lives on lane i + 16k, B[k][j] on lane j + 16k; this lane owns D[4g + r][col].
-        // k ascending with one fmaf per product = the MFMA's documented k-ordered fmaf chain.
-        const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4;
+// "MFMA off" validation path: the same contraction with cross-lane reads on the VALU.
+// A[i][k] lives on lane i + 16k, B[k][j] on lane j + 16k; this lane owns D[4g + r][col].
+// k ascending with one fmaf per product = the MFMA's documented k-ordered fmaf chain.
+// Deliberately NOT inlined: it is a baseline, and one out-of-line copy keeps the build fast.
+__device__ __attribute__((noinline)) inline f32x4 mma_16x16x4_valu(float a, float b, f32x4 c) {
+    const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float bk = __shfl(b, col + 16 * k, 64);
+    for (int k = 0; k < 4; ++k) {
+        const float bk = __shfl(b, col + 16 * k, 64);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) c[r] = fmaf(__shfl(a, 4 * g + r + 16 * k, 64), bk, c[r]);
-        }
-        return c;
+        for (int r = 0; r < 4; ++r) c[r] = fmaf(__shfl(a, 4 * g + r + 16 * k, 64), bk, c[r]);
     }
+    return c;
 }
 
-AC_DI float act_tanh(float x) { return tanhf(x); }
+template <bool USE_MFMA> AC_DI f32x4 mma_16x16x4(float a, float b, f32x4 c) {
+    if constexpr (USE_MFMA) return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    else return mma_16x16x4_valu(a, b, c);
+}
+
+// Branch-free tanh(x) = 1 - 2 / (1 + e^{2x}): one v_exp_f32 and one v_rcp_f32, so it can sit between MFMAs
+// (ocml tanhf branches on |x|).  Saturates correctly (e^{2x} -> inf gives 1, -> 0 gives -1), NaN propagates;
+// absolute error <= ~1.5e-7 (the 1 - 2/(...) cancellation near 0 costs relative, not absolute, accuracy).
+AC_DI float act_tanh(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // 2^(2x log2 e)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
 // Copy `bytes` (a multiple of 1024: the host pads every layer block to whole pieces) from global to
 // LDS with LDS-DMA.  Every wave of the workgroup takes 1-KiB pieces round-robin; a piece is one
@@ -112,14 +120,31 @@ struct MlpEngine {
     // Must run before the wave exits: an LDS-DMA prefetch may still be in flight.
     AC_DI void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+    // Epilogue of one output tile: activation on the value slab, act'(h) scaling on a tangent slab.
+    template <int NT>
+    AC_DI void epilogue_tile(int s, int nt, const f32x4 (&o)[NT], int act) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (s == 0) {
+                a[0][nt][r] = act ? act_tanh(o[nt][r]) : o[nt][r];
+            } else {
+                const float h = a[0][nt][r];  // already the NEW value activation
+                a[s][nt][r] = act ? o[nt][r] * fmaf(-h, h, 1.0f) : o[nt][r];
+            }
+        }
+    }
+
     // CNT output tiles (independent accumulators) x KT k-tiles for slab s; straight-line code, the next
-    // k-tile's A fragments are fetched (ds_read_b128) while the current one's MFMAs issue.
+    // k-tile's A fragments are fetched (ds_read_b128) while the current one's MFMAs issue.  The epilogue of
+    // the PREVIOUS slab (VALU / transcendental work, independent of this slab's MFMAs) is spread over the
+    // k-tile blocks so it issues in the shadow of the matrix pipe instead of after it.
     template <int CNT, int KT, int NT>
     AC_DI void gemm_chunk(const f32x4* __restrict__ wf, const f32x4* __restrict__ bias4, int s, int nc, f32x4 (&o)[NT],
-                          const float (&in)[WT][4]) {
+                          const float (&in)[WT][4], const f32x4 (&oprev)[NT], int act) {
         // The chunks of a layer are mutually independent; without a fence the machine scheduler interleaves
         // them across the whole straight-line layer and the live accumulators no longer fit the register file.
         __builtin_amdgcn_sched_barrier(0);
+        constexpr int kBlocks = (NT / CNT) * KT;  // k-tile blocks per slab
         f32x4 acc[CNT];
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
@@ -134,11 +159,20 @@ struct MlpEngine {
             if (kt + 1 < KT) {
 #pragma unroll
                 for (int i = 0; i < CNT; ++i) wnext[i] = wf[((nc + i) * KT + kt + 1) * 64];
+                // pin the fetch of the NEXT k-tile's fragments ahead of this k-tile's MFMAs (hipcc otherwise sinks
+                // the ds_reads to just before their use and waits lgkmcnt(0) with the matrix pipe idle)
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int i = 0; i < CNT; ++i) acc[i] = mma_16x16x4<USE_MFMA>(wcur[i][r], in[kt][r], acc[i]);
+            if (s > 0) {  // previous slab's epilogue tiles assigned to this block
+                const int blk = (nc / CNT) * KT + kt;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (t * kBlocks / NT == blk) epilogue_tile<NT>(s - 1, t, oprev, act);
+            }
             if (kt + 1 < KT) {
 #pragma unroll
                 for (int i = 0; i < CNT; ++i) wcur[i] = wnext[i];
@@ -158,25 +192,15 @@ struct MlpEngine {
         const f32x4* bias4 = reinterpret_cast<const f32x4*>(wl + NT * KT * 1024);
         constexpr int C = NT < CH ? NT : CH;
         static_assert(NT % C == 0, "tile count must be a multiple of the chunk");
+        f32x4 o[2][NT];  // ping-pong: slab s accumulates into o[s&1] while slab s-1's epilogue drains o[(s-1)&1]
 #pragma unroll
         for (int s = 0; s < NSLAB; ++s) {
-            f32x4 o[NT];
 #pragma unroll
-            for (int nc = 0; nc < NT; nc += C) gemm_chunk<C, KT, NT>(wf, bias4, s, nc, o, a[s]);
-            // epilogue: activation on the value slab, act'(h) scaling on tangent slabs
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (s == 0) {
-                        a[0][nt][r] = act ? act_tanh(o[nt][r]) : o[nt][r];
-                    } else {
-                        const float h = a[0][nt][r];  // already the NEW value activation
-                        a[s][nt][r] = act ? o[nt][r] * fmaf(-h, h, 1.0f) : o[nt][r];
-                    }
-                }
-            }
+            for (int nc = 0; nc < NT; nc += C)
+                gemm_chunk<C, KT, NT>(wf, bias4, s, nc, o[s & 1], a[s], o[(s + 1) & 1], act);
         }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) epilogue_tile<NT>(NSLAB - 1, nt, o[(NSLAB - 1) & 1], act);
     }
 
     // LDS address of layer l's block; for a streamed layer: wait for its DMA, then (the barrier having
