@@ -94,9 +94,10 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_fwd(const DevParams P, const M
     }
 }
 
-// Sequential rollout: one wave (16 instances) per workgroup so B = 4096 spreads over 256 CUs.
+// Sequential rollout, one wave per 16 instances (launched with 4-wave workgroups).  Used for very large batches
+// and for the VALU validation path; moderate batches take k_nn_rollout_coop below.
 template <int WT, bool USE_MFMA>
-__global__ __launch_bounds__(64, 1) void k_nn_rollout(const DevParams P, const MlpPlan plan,
+__global__ __launch_bounds__(kBlock, 1) void k_nn_rollout(const DevParams P, const MlpPlan plan,
                                                       const float* __restrict__ blob, const float* __restrict__ X0,
                                                       const float* __restrict__ U, float dt, long B, long H,
                                                       float* __restrict__ Xout) {
@@ -123,6 +124,47 @@ __global__ __launch_bounds__(64, 1) void k_nn_rollout(const DevParams P, const M
             float* o = Xout + (k + 1) * 13 * B;
 #pragma unroll
             for (int r = 0; r < 13; ++r) o[(long)r * B + w.unit] = (float)xa[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 7; ++r) u[r] = un[r];
+    }
+    eng.drain();
+}
+
+// Cooperative rollout: one 4-wave workgroup per 16 instances (see MlpEngineCoop).  Every wave integrates the same
+// 16 instances (the rigid-body part is tiny); wave 0 writes the trajectory.
+template <int WT, bool USE_MFMA>
+__global__ __launch_bounds__(kBlock, 1) void k_nn_rollout_coop(const DevParams P, const MlpPlan plan,
+                                                               const float* __restrict__ blob,
+                                                               const float* __restrict__ X0,
+                                                               const float* __restrict__ U, float dt, long B, long H,
+                                                               float* __restrict__ Xout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MlpEngineCoop<WT, USE_MFMA> eng(plan, blob, smem);
+    eng.load_weights();
+    const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const long raw = (long)blockIdx.x * 16 + col;
+    const bool live = raw < B;
+    const long unit = live ? raw : B - 1;
+    float x[13], u[7], un[7];
+    load_rows<13>(X0, B, unit, x);
+    const bool writer = live && g == 0 && wave == 0;
+    double xa[13];
+#pragma unroll
+    for (int r = 0; r < 13; ++r) xa[r] = (double)x[r];
+    if (writer) {
+#pragma unroll
+        for (int r = 0; r < 13; ++r) Xout[(long)r * B + unit] = x[r];
+    }
+    if (H > 0) load_rows<7>(U, B, unit, u);
+    MlpCoeffs<MlpEngineCoop<WT, USE_MFMA>> coeffs(eng);
+    for (long k = 0; k < H; ++k) {
+        if (k + 1 < H) load_rows<7>(U + (k + 1) * 7 * B, B, unit, un);
+        state_update_carry(P, coeffs, xa, u, dt);
+        if (writer) {
+            float* o = Xout + (k + 1) * 13 * B;
+#pragma unroll
+            for (int r = 0; r < 13; ++r) o[(long)r * B + unit] = (float)xa[r];
         }
 #pragma unroll
         for (int r = 0; r < 7; ++r) u[r] = un[r];

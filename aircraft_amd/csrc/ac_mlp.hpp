@@ -257,6 +257,126 @@ struct MlpEngine {
     }
 };
 
+// ---- cooperative forward engine (rollouts) -----------------------------------------------------
+// A rollout is sequential in k, so only B instances are parallel: at B = 4096 one wave per 16 instances is
+// 256 waves on 1024 SIMDs, and every lone wave has to stream its own 65 KiB of weights per layer.  Here the
+// FOUR waves of a workgroup share one 16-instance slab: wave w computes output tiles [w*NT/4, (w+1)*NT/4) of
+// every layer (all waves hold the full input slab in registers), the tiles are exchanged through an 8 KiB LDS
+// buffer, and the weight ring is filled by all four waves.  4x the parallelism per instance, 1/4 of the MFMA
+// chain per wave; the price is two workgroup barriers per layer.
+template <int WT, bool USE_MFMA>
+struct MlpEngineCoop {
+    static constexpr bool kTangent = false;
+    static constexpr int kWaves = 4;
+
+    float a[WT][4];  // full input slab of the current layer (values only)
+    const MlpPlan& plan;
+    const float* __restrict__ gblob;
+    char* lds;
+    f32x4* xbuf;  // [tile][lane] exchange buffer, 1 KiB per tile
+    int lane, g, wave;
+    int ring_pos;
+
+    AC_DI MlpEngineCoop(const MlpPlan& pl, const float* blob, char* lds_base)
+        : plan(pl), gblob(blob), lds(lds_base), ring_pos(0) {
+        lane = threadIdx.x & 63; g = lane >> 4; wave = threadIdx.x >> 6;
+        xbuf = reinterpret_cast<f32x4*>(lds_base + pl.lds_total);  // the host reserves WT KiB behind the weights
+    }
+
+    AC_DI int streamed_layer(int idx) const {
+        int seen = 0;
+        for (int l = 0; l < plan.n_layers; ++l)
+            if (plan.lds_off[l] < 0) { if (seen == idx) return l; ++seen; }
+        return -1;
+    }
+
+    // resident layers + the first TWO streamed layers (one per ring slot)
+    AC_DI void load_weights() {
+        for (int l = 0; l < plan.n_layers; ++l)
+            if (plan.lds_off[l] >= 0) lds_dma_copy(gblob + plan.g_off[l], lds + plan.lds_off[l], plan.bytes[l], wave, kWaves, lane);
+        if (plan.n_streamed > 0) {
+            for (int i = 0; i < 2; ++i) {  // slot i holds the (i mod n_streamed)-th streamed layer
+                const int l = streamed_layer(i % plan.n_streamed);
+                lds_dma_copy(gblob + plan.g_off[l], lds + plan.ring_off[i], plan.bytes[l], wave, kWaves, lane);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    AC_DI void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+    template <int KT, int NT>
+    AC_DI void layer(int l, int act) {
+        const bool streamed = plan.lds_off[l] < 0;
+        const char* wl = streamed ? lds + plan.ring_off[ring_pos & 1] : lds + plan.lds_off[l];
+        const f32x4* wf = reinterpret_cast<const f32x4*>(wl) + lane;
+        const f32x4* bias4 = reinterpret_cast<const f32x4*>(wl + NT * KT * 1024);
+        constexpr int T = NT >= kWaves ? NT / kWaves : 1;  // tiles per wave
+        const int t0 = wave * T;
+        if (t0 < NT) {  // wave-uniform
+            f32x4 acc[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) acc[i] = bias4[(t0 + i) * 4 + g];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                f32x4 w[T];
+#pragma unroll
+                for (int i = 0; i < T; ++i) w[i] = wf[((t0 + i) * KT + kt) * 64];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < T; ++i) acc[i] = mma_16x16x4<USE_MFMA>(w[i][r], a[kt][r], acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                f32x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = act ? act_tanh(acc[i][r]) : acc[i][r];
+                xbuf[(t0 + i) * 64 + lane] = h;
+            }
+        }
+        // one barrier: every tile of this layer is in xbuf, every wave is done with this layer's weights, and
+        // (vmcnt) every wave's pieces of the ring slot that the NEXT streamed layer needs have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (streamed) {  // this layer's slot is free: request the streamed layer after next into it
+            const int nl = streamed_layer((ring_pos + 2) % plan.n_streamed);
+            lds_dma_copy(gblob + plan.g_off[nl], lds + plan.ring_off[ring_pos & 1], plan.bytes[nl], wave, kWaves, lane);
+            ++ring_pos;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 h = xbuf[t * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[t][r] = h[r];
+        }
+        __syncthreads();  // xbuf may be overwritten by the next layer only after everyone has read it
+    }
+
+    AC_DI void forward(const float z[5], float y[6], float (*)[5]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v = (row == k) ? z[k] : v;
+            a[0][r] = v;
+        }
+        const int L = plan.n_layers;
+        if (L == 1) {
+            layer<1, 1>(0, plan.act[0]);
+        } else {
+            layer<1, WT>(0, plan.act[0]);
+#pragma nounroll
+            for (int l = 1; l < L - 1; ++l) layer<WT, WT>(l, plan.act[l]);
+            layer<WT, 1>(L - 1, plan.act[L - 1]);
+        }
+        const int col = lane & 15;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) y[k] = __shfl(a[0][k & 3], col + 16 * (k >> 2), 64);
+    }
+};
+
 // Coefficient provider that plugs the engine into state_derivative().  prefetch() runs the network on the
 // primal aerodynamic inputs of the stage state and keeps only y[6] (+ J[6][5]); operator() then applies the
 // output scaler and, for duals, the chain rule  dC = J . d(inputs)  — the custom-Jacobian rule l4casadi

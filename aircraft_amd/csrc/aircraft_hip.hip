@@ -360,16 +360,36 @@ int ac_rollout_f32(ac_handle* h, const float* X0, const float* U, float dt, long
     if (B == 0) return AC_OK;
     hipStream_t st = (hipStream_t)stream;
     if (h->dp.p.model_kind == AC_MODEL_NN) {
-        const int grid = (int)((B + 15) / 16);
+        const long groups = (B + 15) / 16;  // 16 instances per wave-slab
         bool launched = false;
-        AC_NN_CASE(2, true, (k_nn_rollout<2, true>), grid, 64, X0, U, dt, B, H, Xout)
-        AC_NN_CASE(4, true, (k_nn_rollout<4, true>), grid, 64, X0, U, dt, B, H, Xout)
-        AC_NN_CASE(8, true, (k_nn_rollout<8, true>), grid, 64, X0, U, dt, B, H, Xout)
-        AC_NN_CASE(2, false, (k_nn_rollout<2, false>), grid, 64, X0, U, dt, B, H, Xout)
-        AC_NN_CASE(4, false, (k_nn_rollout<4, false>), grid, 64, X0, U, dt, B, H, Xout)
-        AC_NN_CASE(8, false, (k_nn_rollout<8, false>), grid, 64, X0, U, dt, B, H, Xout)
+        if (h->use_mfma && groups < 4096) {
+            // cooperative: one 4-wave workgroup per 16 instances (4x the parallelism per instance)
+            const int grid = (int)groups;
+            const int lds = h->plan.lds_total + h->wt * 1024;  // + the activation exchange buffer
+#define AC_COOP_CASE(WT_)                                                                                   \
+            if (h->wt == WT_) {                                                                             \
+                auto kern = k_nn_rollout_coop<WT_, true>;                                                   \
+                int rc_ = set_lds_limit(kern, lds);                                                         \
+                if (rc_ != AC_OK) return rc_;                                                               \
+                hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->plan, h->d_blob, X0, U, dt, B, H, Xout); \
+                launched = true;                                                                            \
+            }
+            AC_COOP_CASE(2) AC_COOP_CASE(4) AC_COOP_CASE(8)
+#undef AC_COOP_CASE
+            if (!launched) return AC_ERR_UNSUPPORTED;
+            note_launch(h, "k_nn_rollout_coop", grid, kBlock, lds);
+            AC_HIP(hipGetLastError());
+            return AC_OK;
+        }
+        const int grid = (int)((groups + 3) / 4);
+        AC_NN_CASE(2, true, (k_nn_rollout<2, true>), grid, kBlock, X0, U, dt, B, H, Xout)
+        AC_NN_CASE(4, true, (k_nn_rollout<4, true>), grid, kBlock, X0, U, dt, B, H, Xout)
+        AC_NN_CASE(8, true, (k_nn_rollout<8, true>), grid, kBlock, X0, U, dt, B, H, Xout)
+        AC_NN_CASE(2, false, (k_nn_rollout<2, false>), grid, kBlock, X0, U, dt, B, H, Xout)
+        AC_NN_CASE(4, false, (k_nn_rollout<4, false>), grid, kBlock, X0, U, dt, B, H, Xout)
+        AC_NN_CASE(8, false, (k_nn_rollout<8, false>), grid, kBlock, X0, U, dt, B, H, Xout)
         if (!launched) return AC_ERR_UNSUPPORTED;
-        note_launch(h, "k_nn_rollout", grid, 64, h->plan.lds_total);
+        note_launch(h, "k_nn_rollout", grid, kBlock, h->plan.lds_total);
         AC_HIP(hipGetLastError());
         return AC_OK;
     }

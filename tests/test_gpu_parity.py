@@ -160,7 +160,7 @@ def test_rollout_in_envelope(gpu):
 # (model, B, H).  The reference's networks/linearised.csv has a positive C_Z-alpha slope (anti-lift): that model
 # diverges to inf within ~20 steps, so it is rolled out over a short horizon only.
 ROLLOUT_CASES = [("default", 257, 50), ("linear", 100, 8), ("poly", 257, 50), ("real", 600, 50),
-                 ("cfg2_3x64", 256, 50), ("cfg3_4x128", 64, 50), ("cfg3_4x128", 320, 100)]
+                 ("cfg2_3x64", 256, 50), ("cfg2_3x64_valu", 70, 20), ("cfg3_4x128", 64, 50), ("cfg3_4x128", 320, 100)]
 
 
 @pytest.mark.parametrize("model,B,H", ROLLOUT_CASES)

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the headline): every mode of the hot path on one MI355X.
+Prints one JSON object per line; run on the GPU box."""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from aircraft_amd import Aircraft, AircraftConfiguration, AircraftOpts, MlpData
+from aircraft_amd.control import MultipleShooting
+from aircraft_amd.synthetic import GLIDER, synthetic_controls, synthetic_states
+from tests.helpers import make_aircraft
+
+dev = torch.device("cuda", 0)
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters  # ms
+
+def problem(B, H, seed=42):
+    rng = np.random.default_rng(seed)
+    Xh = synthetic_states(B * (H + 1), rng).reshape(13, H + 1, B).transpose(1, 0, 2)
+    Uh = synthetic_controls(H, B, rng)
+    return (torch.from_numpy(np.ascontiguousarray(Xh, dtype=np.float32)).to(dev),
+            torch.from_numpy(np.ascontiguousarray(Uh, dtype=np.float32)).to(dev))
+
+def run(name, ac, B, H, iters=10):
+    ms = MultipleShooting(system=ac, dt=0.01, num_nodes=H, opts={"quaternion": "integration"})
+    X, U = problem(B, H)
+    F = torch.empty((H, 13, B), device=dev); A = torch.empty((H, 13, 13, B), device=dev); Bm = torch.empty((H, 13, 7, B), device=dev)
+    traj = torch.empty((H + 1, 13, B), device=dev)
+    x0 = X[0].contiguous()
+    t_sens = timeit(lambda: ms.linearise(X, U, out=(F, A, Bm, None)), iters)
+    k_sens = ac.last_launch()
+    t_fwd = timeit(lambda: ms.propagate(X, U, out=F), iters)
+    k_fwd = ac.last_launch()
+    t_roll = timeit(lambda: ms.rollout(x0, U, out=traj), max(2, iters // 2))
+    k_roll = ac.last_launch()
+    n = B * H
+    print(json.dumps({"case": name, "B": B, "H": H,
+                      "sens_steps_per_s": n / t_sens * 1e3, "sens_ms": t_sens, "sens_kernel": k_sens[0],
+                      "fwd_steps_per_s": n / t_fwd * 1e3, "fwd_ms": t_fwd,
+                      "rollout_steps_per_s": n / t_roll * 1e3, "rollout_ms": t_roll, "rollout_grid": k_roll[1]}), flush=True)
+
+which = sys.argv[1:] or ["cfg3", "cfg2", "cfg2_valu", "real", "poly", "default", "linear", "cfg5"]
+if "cfg3" in which: run("cfg3 4x128 mfma", make_aircraft("nn", hidden=(128,) * 4), 4096, 50)
+if "cfg2" in which:
+    run("cfg2 3x64 mfma B=256", make_aircraft("nn", hidden=(64,) * 3), 256, 50)
+    run("cfg2 3x64 mfma B=4096", make_aircraft("nn", hidden=(64,) * 3), 4096, 50)
+if "cfg2_valu" in which:
+    run("cfg2 3x64 VALU (mfma off) B=256", make_aircraft("nn", hidden=(64,) * 3, use_mfma=False), 256, 50, iters=4)
+    run("cfg2 3x64 VALU (mfma off) B=4096", make_aircraft("nn", hidden=(64,) * 3, use_mfma=False), 4096, 50, iters=3)
+if "real" in which: run("real 5-16-32-6", make_aircraft("nn"), 4096, 50)
+for m in ("poly", "default", "linear"):
+    if m in which: run(m, make_aircraft(m), 4096, 50)
+if "cfg4" in which: run("cfg4 per-GPU shard 4x128 B=2048 H=100", make_aircraft("nn", hidden=(128,) * 4), 2048, 100)
+if "cfg5" in which:
+    # receding-horizon closed loop: sequential solves, each = re-rollout from the shifted state + linearise
+    ac = make_aircraft("nn", hidden=(128,) * 4)
+    B, H, nsolve = 1024, 50, 200
+    ms = MultipleShooting(system=ac, dt=0.01, num_nodes=H, opts={"quaternion": "integration"})
+    X, U = problem(B, H)
+    traj = torch.empty((H + 1, 13, B), device=dev); x0 = X[0].contiguous().clone()
+    F = torch.empty((H, 13, B), device=dev); A = torch.empty((H, 13, 13, B), device=dev); Bm = torch.empty((H, 13, 7, B), device=dev)
+    def solve():
+        ms.rollout(x0, U, out=traj)
+        ms.linearise(traj, U, out=(F, A, Bm, None))
+        x0.copy_(traj[H - 30])  # shift by N - overlap (main/mhe/mhtt.py:86-88)
+    t_eager = timeit(solve, 20, 3)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        solve()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            solve()
+    torch.cuda.current_stream().wait_stream(s)
+    t_graph = timeit(lambda: g.replay(), 20, 3)
+    print(json.dumps({"case": "cfg5 closed loop B=1024 H=50 (rollout + linearise + shift) per solve",
+                      "eager_ms": t_eager, "graph_ms": t_graph, "solves_per_s_graph": 1e3 / t_graph,
+                      "steps_per_s_graph": 2 * B * H / t_graph * 1e3}), flush=True)
