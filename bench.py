@@ -147,6 +147,13 @@ def main():
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
+    # HBM traffic of the dominant kernel from the PMC passes (FETCH_SIZE x2 per the gfx950 guide + WRITE_SIZE, calibrated
+    # on a known-byte-count kernel of the same access pattern): collected separately with rocprofv3 --pmc and committed
+    # under profiles/; it applies to the default workload only.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tpath) and (B, H, hidden) == (4096, 50, (128, 128, 128, 128)) and not args.no_mfma:
+        traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
     units_per_step = B * H * world
     value = units_per_step * args.steps / elapsed
     F_mlp = mlp.flops_forward()
@@ -166,7 +173,9 @@ def main():
                        "batch_per_gpu": B, "horizon": H, "units_per_step": units_per_step,
                        "mfma": not args.no_mfma, "parallelism": f"instances sharded x{world}, all-gather of best record"},
             "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
+                         "algorithmic_bytes_per_launch": bytes_unit * B * H,
                          "kernel": name, "kernel_ms": kern_ms, "grid": grid, "block": block, "lds_bytes": lds,
                          "flops_per_unit": flops_unit, "hbm_bytes_per_unit": bytes_unit,
                          "hbm_achieved_GBs": achieved_gbs, "hbm_frac": achieved_gbs / PEAK_HBM_GBS},

@@ -1,0 +1,169 @@
+"""GPU tests at BASELINE.json's full sizes (cfg3: B=4096, H=50, 4x128 MLP; cfg4 shard: B=2048, H=100) through
+size-independent properties, plus an oracle spot check on a random sample of the full-size result."""
+import numpy as np
+import pytest
+
+from tests.helpers import block_rel_err, f32_exact, make_aircraft, make_oracle, rel_fro
+from aircraft_amd.synthetic import synthetic_controls, synthetic_states
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(B, H, gpu, seed=42):
+    import torch
+
+    rng = np.random.default_rng(seed)
+    Xh = f32_exact(synthetic_states(B * (H + 1), rng).reshape(13, H + 1, B).transpose(1, 0, 2))
+    Uh = f32_exact(synthetic_controls(H, B, rng))
+    return Xh, Uh, torch.from_numpy(np.ascontiguousarray(Xh, dtype=np.float32)).to(gpu), \
+        torch.from_numpy(np.ascontiguousarray(Uh, dtype=np.float32)).to(gpu)
+
+
+@pytest.fixture(scope="module")
+def cfg3(gpu):
+    from aircraft_amd.control import MultipleShooting
+
+    ac = make_aircraft("nn", hidden=(128, 128, 128, 128))
+    ms = MultipleShooting(system=ac, dt=0.01, num_nodes=50, opts={"quaternion": "integration"})
+    Xh, Uh, X, U = _problem(4096, 50, gpu)
+    F, A, Bm, c = ms.linearise(X, U)
+    return dict(ac=ac, ms=ms, Xh=Xh, Uh=Uh, X=X, U=U, F=F, A=A, Bm=Bm, c=c)
+
+
+def test_cfg3_oracle_spot_check(cfg3):
+    """512 random (instance, node) units of the 204 800 against the float64 oracle."""
+    rng = np.random.default_rng(0)
+    k = rng.integers(0, 50, 512); b = rng.integers(0, 4096, 512)
+    Xs = np.ascontiguousarray(cfg3["Xh"][k, :, b].T); Us = np.ascontiguousarray(cfg3["Uh"][k, :, b].T)
+    Xr, Ar, Br, cr = make_oracle(cfg3["ac"]).step_sens(Xs, Us, 0.01)
+    F = cfg3["F"].cpu().numpy()[k, :, b].T
+    A = cfg3["A"].cpu().numpy()[k, :, :, b].transpose(1, 2, 0)
+    Bm = cfg3["Bm"].cpu().numpy()[k, :, :, b].transpose(1, 2, 0)
+    c = cfg3["c"].cpu().numpy()[k, :, b].T
+    assert block_rel_err(F, Xr) < 1e-5
+    assert rel_fro(A, Ar) < 1e-4 and rel_fro(Bm, Br) < 1e-4 and rel_fro(c, cr) < 1e-4
+
+
+def test_cfg3_deterministic_and_shard_invariant(cfg3):
+    """Same inputs -> same bits; and a unit's result does not depend on which batch it is evaluated in (the
+    multi-GPU sharding relies on it): the full batch equals its two halves evaluated separately."""
+    import torch
+
+    ms, X, U = cfg3["ms"], cfg3["X"], cfg3["U"]
+    F2, A2, B2, c2 = ms.linearise(X, U)
+    assert torch.equal(F2, cfg3["F"]) and torch.equal(A2, cfg3["A"]) and torch.equal(B2, cfg3["Bm"])
+    for lo, hi in ((0, 2048), (2048, 4096)):
+        Fh, Ah, Bh, ch = ms.linearise(X[:, :, lo:hi].contiguous(), U[:, :, lo:hi].contiguous())
+        assert torch.equal(Fh, cfg3["F"][:, :, lo:hi]) and torch.equal(Ah, cfg3["A"][:, :, :, lo:hi])
+        assert torch.equal(Bh, cfg3["Bm"][:, :, :, lo:hi]) and torch.equal(ch, cfg3["c"][:, :, lo:hi])
+
+
+def test_cfg3_structure_and_norm(cfg3):
+    import torch
+
+    F, A, Bm = cfg3["F"], cfg3["A"], cfg3["Bm"]
+    assert torch.isfinite(F).all() and torch.isfinite(A).all() and torch.isfinite(Bm).all()
+    assert float((F[:, 6:10].norm(dim=1) - 1).abs().max()) < 1e-6  # q normalised (quaternion == 'integration')
+    eye = torch.eye(13, device=A.device)[:, :3]
+    assert torch.equal(A[:, :, :3, :], eye[None, :, :, None].expand(50, 13, 3, 4096))  # dF/dp = [I; 0]
+    assert not Bm[:, :, 3:6, :].any()  # dF/dthrust = 0
+    # the normalised quaternion is orthogonal to its own tangent: q+^T dq+/d(anything) = 0
+    qT = F[:, 6:10]
+    assert float(torch.einsum("kib,kijb->kjb", qT, A[:, 6:10]).abs().max()) < 2e-5
+    assert float(torch.einsum("kib,kijb->kjb", qT, Bm[:, 6:10]).abs().max()) < 2e-5
+
+
+def test_cfg3_jacobian_is_the_derivative_of_the_gpu_step(cfg3):
+    """Linearity check at full size, no oracle: F(x + d) - F(x - d) ~= 2 A d along a random direction."""
+    import torch
+
+    ms, X, U = cfg3["ms"], cfg3["X"], cfg3["U"]
+    g = torch.Generator(device="cpu").manual_seed(3)
+    d = torch.randn(13, generator=g).to(X.device) * torch.tensor([1, 1, 1, 0.05, 0.05, 0.05, 2e-3, 2e-3, 2e-3, 2e-3, 0.02, 0.02, 0.02], device=X.device)
+    dX = d[None, :, None].expand(50, 13, 4096)
+    Fp = ms.propagate((X[:50] + dX).contiguous(), U)
+    Fm = ms.propagate((X[:50] - dX).contiguous(), U)
+    lin = 2 * torch.einsum("kijb,j->kib", cfg3["A"], d)
+    num = (Fp - Fm)
+    scale = lin.abs().amax(dim=(0, 2), keepdim=True).clamp_min(1e-6)
+    # fp32 central difference: truncation + cancellation noise, so a coarse bound — but a wrong Jacobian is O(1) off
+    assert float(((num - lin).abs() / scale).quantile(0.999)) < 5e-2
+    assert float(((num - lin).abs() / scale).median()) < 2e-3
+
+
+def test_cfg3_rollout_chains_the_step(cfg3):
+    """Full-size rollout (cooperative kernel): every node is the step of its predecessor to fp32 rounding."""
+    import torch
+
+    ms, X, U = cfg3["ms"], cfg3["X"], cfg3["U"]
+    traj = ms.rollout(X[0].contiguous(), U)
+    assert traj.shape == (51, 13, 4096) and torch.equal(traj[0], X[0])
+    Fchain = ms.propagate(traj, U)
+    fin = torch.isfinite(traj[1:]).all(dim=1) & torch.isfinite(Fchain).all(dim=1)
+    d = (Fchain - traj[1:]).abs()
+    scale = traj[1:].abs().clamp_min(1.0)
+    assert float((d / scale)[fin[:, None, :].expand_as(d)].max()) < 5e-6
+    assert float((traj[-1, 6:10].norm(dim=0) - 1).abs()[fin[-1]].max()) < 1e-6
+
+
+def test_cfg4_shard_shape(gpu):
+    """cfg4: one rank's shard of B=16384 (2048 instances), H=100: shapes, finiteness, oracle sample."""
+    from aircraft_amd.control import MultipleShooting
+    from aircraft_amd.distributed import shard_bounds
+
+    lo, hi = shard_bounds(16384, 5, 8)
+    assert hi - lo == 2048
+    ac = make_aircraft("nn", hidden=(128, 128, 128, 128))
+    ms = MultipleShooting(system=ac, dt=0.01, num_nodes=100, opts={"quaternion": "integration"})
+    Xh, Uh, X, U = _problem(2048, 100, gpu, seed=5)
+    F, A, Bm, c = ms.linearise(X, U, want_c=False)
+    assert F.shape == (100, 13, 2048) and A.shape == (100, 13, 13, 2048) and c is None
+    rng = np.random.default_rng(1)
+    k = rng.integers(0, 100, 128); b = rng.integers(0, 2048, 128)
+    Xr, Ar, Br, _ = make_oracle(ac).step_sens(np.ascontiguousarray(Xh[k, :, b].T), np.ascontiguousarray(Uh[k, :, b].T), 0.01)
+    assert block_rel_err(F.cpu().numpy()[k, :, b].T, Xr) < 1e-5
+    assert rel_fro(A.cpu().numpy()[k, :, :, b].transpose(1, 2, 0), Ar) < 1e-4
+
+
+def test_hipgraph_capture_of_the_inner_step(gpu):
+    """cfg5: the rollout + linearise step of the receding-horizon loop is hipGraph-capturable (no allocation or
+    synchronisation inside the entry points) and replays bit-identically."""
+    import torch
+    from aircraft_amd.control import MultipleShooting
+
+    ac = make_aircraft("nn", hidden=(128, 128, 128, 128))
+    B, H = 1024, 50
+    ms = MultipleShooting(system=ac, dt=0.01, num_nodes=H, opts={"quaternion": "integration"})
+    _, _, X, U = _problem(B, H, gpu, seed=9)
+    x0 = X[0].contiguous().clone()
+    traj = torch.empty((H + 1, 13, B), device=gpu)
+    out = (torch.empty((H, 13, B), device=gpu), torch.empty((H, 13, 13, B), device=gpu),
+           torch.empty((H, 13, 7, B), device=gpu), None)
+
+    def step():
+        ms.rollout(x0, U, out=traj)
+        ms.linearise(traj, U, out=out)
+
+    step()
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in (traj, out[0], out[1], out[2])]
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    for t in (traj, out[0], out[1], out[2]):
+        t.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for got, want in zip((traj, out[0], out[1], out[2]), ref):
+        assert torch.equal(got, want)
+    # replay with a new initial state written into the captured buffer
+    x0.copy_(X[7])
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(traj[0], X[7]) and not torch.equal(traj[1], ref[0][1])
