@@ -36,6 +36,12 @@ class AcParams(C.Structure):
     ]
 
 
+class IlqrCost(C.Structure):
+    """struct ac_ilqr_cost (include/aircraft_hip.h)."""
+    _fields_ = [("q", C.c_float * 13), ("qf", C.c_float * 13), ("r", C.c_float * 7), ("x_ref", C.c_float * 13),
+                ("x_goal", C.c_float * 13), ("u_min", C.c_float * 7), ("u_max", C.c_float * 7), ("reg", C.c_float)]
+
+
 # every symbol include/aircraft_hip.h declares, with its prototype
 _FP = C.POINTER(C.c_float)
 _VP = C.c_void_p
@@ -55,6 +61,10 @@ PROTOTYPES = {
     "ac_shoot_sens_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP, _VP]),
     "ac_aero_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, _VP, _VP]),
     "ac_traj_cost_f32": (C.c_int, [_VP, _VP, C.c_long, C.c_long, _FP, C.c_float, C.c_float, _VP, _VP]),
+    "ac_ilqr_backward_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP]),
+    "ac_ilqr_cost_f32": (C.c_int, [_VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
+    "ac_rollout_policy_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _FP, C.c_int, C.c_float, C.c_long, C.c_long,
+                                        _VP, _VP, _VP]),
     "ac_last_error": (C.c_char_p, []),
     "ac_version": (C.c_char_p, []),
     "ac_device_arch": (C.c_int, [C.c_char_p, C.c_size_t]),

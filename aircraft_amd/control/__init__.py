@@ -1,3 +1,4 @@
 from .base import MultipleShooting
+from .ilqr import ILQR, QuadraticCost
 
-__all__ = ["MultipleShooting"]
+__all__ = ["MultipleShooting", "ILQR", "QuadraticCost"]

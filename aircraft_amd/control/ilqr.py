@@ -1,0 +1,161 @@
+"""Batched iLQR / Gauss-Newton sweep on top of the multiple-shooting linearisation.
+
+The reference formulates its MPC as an NLP and hands it to IPOPT, one instance at a time
+(src/aircraft/control/base.py:455-477).  This module is the build-side solver that turns the hot-path kernels
+(rollout, step sensitivities) into B simultaneous MPC solves — random restarts / independent instances — playing the
+`loss` and control-limit roles of the reference's controllers (control/base.py:323-337, control/aircraft.py:29-41,
+main/control/control.py:35-70: goal term on the final position, actuation penalty, surface limits).
+
+One iteration = linearise (ac_shoot_sens_f32) -> backward Riccati pass (ac_ilqr_backward_f32) -> closed-loop rollouts for
+every line-search step alpha in ONE launch (ac_rollout_policy_f32) -> cost (ac_ilqr_cost_f32) -> per-instance argmin.
+Everything stays on the device; torch is used for buffers and the final select only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .. import _lib
+from .base import MultipleShooting
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+@dataclass
+class QuadraticCost:
+    """J = sum_k 1/2 (x_k - x_ref)' diag(q) (x_k - x_ref) + 1/2 u_k' diag(r) u_k + 1/2 (x_N - x_goal)' diag(qf) (x_N - x_goal)."""
+    q: Sequence[float] = field(default_factory=lambda: [0.0] * 13)
+    qf: Sequence[float] = field(default_factory=lambda: [0.0] * 13)
+    r: Sequence[float] = field(default_factory=lambda: [1e-2] * 7)
+    x_ref: Sequence[float] = field(default_factory=lambda: [0.0] * 13)
+    x_goal: Sequence[float] = field(default_factory=lambda: [0.0] * 13)
+    # control box: aileron/elevator/rudder +-5 deg (control/aircraft.py:26), thrust disabled, flaps in [0, 1]
+    u_min: Sequence[float] = field(default_factory=lambda: [-5, -5, -5, 0, 0, 0, 0])
+    u_max: Sequence[float] = field(default_factory=lambda: [5, 5, 5, 0, 0, 0, 1])
+    reg: float = 1e-3
+
+    @staticmethod
+    def goal(goal_xy, w_goal=1000.0, w_height=1.0, height=None, w_lateral_speed=1000.0, r=1e-2, reg=1e-3):
+        """The shape of Controller.loss (main/control/control.py:35-70): reach goal (x, y) at the final node, keep the
+        final height, damp final lateral/vertical speed, penalise actuation."""
+        c = QuadraticCost(r=[r] * 7, reg=reg)
+        qf = [0.0] * 13; xg = [0.0] * 13
+        qf[0] = qf[1] = 2.0 * w_goal; xg[0], xg[1] = float(goal_xy[0]), float(goal_xy[1])
+        if height is not None:
+            qf[2] = 2.0 * w_height; xg[2] = float(height)
+        qf[4] = qf[5] = 2.0 * w_lateral_speed
+        c.qf, c.x_goal = qf, xg
+        return c
+
+    def struct(self) -> "_lib.IlqrCost":
+        s = _lib.IlqrCost()
+        for name, n in (("q", 13), ("qf", 13), ("r", 7), ("x_ref", 13), ("x_goal", 13), ("u_min", 7), ("u_max", 7)):
+            v = [float(x) for x in getattr(self, name)]
+            assert len(v) == n, name
+            getattr(s, name)[:] = v
+        s.reg = float(self.reg)
+        return s
+
+
+class ILQR(MultipleShooting):
+    def __init__(self, *, system, dt: float = 0.01, num_nodes: int, cost: QuadraticCost, opts: Optional[dict] = None,
+                 alphas: Sequence[float] = (1.0, 0.5, 0.25, 0.1, 0.03)):
+        super().__init__(system=system, dt=dt, num_nodes=num_nodes, opts=opts or {"quaternion": "integration"})
+        assert 1 <= len(alphas) <= 8
+        self.cost = cost
+        self.alphas = [float(a) for a in alphas]
+        self._ws = None
+
+    # ---- device workspace (allocated once per (B, H)) ------------------------------------------------
+    def _workspace(self, B, dev):
+        torch = _torch()
+        H, na = self.num_nodes, len(self.alphas)
+        key = (B, H, na, str(dev))
+        if self._ws is None or self._ws["key"] != key:
+            f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)  # noqa: E731
+            self._ws = dict(key=key, F=f(H, 13, B), A=f(H, 13, 13, B), Bm=f(H, 13, 7, B), K=f(H, 7, 13, B), kff=f(H, 7, B),
+                            dV=f(2, B), Xc=f(H + 1, 13, na * B), Uc=f(H, 7, na * B), Jc=f(na * B), J0=f(B))
+        return self._ws
+
+    def _cstruct(self):
+        return C.byref(self.cost.struct())
+
+    def trajectory_cost(self, X, U, out=None):
+        torch = _torch()
+        lib = self.system._sync()
+        H, B = U.shape[0], U.shape[2]
+        if out is None:
+            out = torch.empty((B,), device=X.device, dtype=torch.float32)
+        _lib.check(lib.ac_ilqr_cost_f32(self.system._handle, self._cstruct(), X.data_ptr(), U.data_ptr(), B, H,
+                                        out.data_ptr(), self.system._stream()), "ac_ilqr_cost_f32")
+        return out
+
+    def backward(self, X, U, A, Bm, out=None):
+        torch = _torch()
+        lib = self.system._sync()
+        H, B = U.shape[0], U.shape[2]
+        if out is None:
+            out = (torch.empty((H, 7, 13, B), device=X.device), torch.empty((H, 7, B), device=X.device),
+                   torch.empty((2, B), device=X.device))
+        K, kff, dV = out
+        _lib.check(lib.ac_ilqr_backward_f32(self.system._handle, self._cstruct(), X.data_ptr(), U.data_ptr(),
+                                            A.data_ptr(), Bm.data_ptr(), B, H, K.data_ptr(), kff.data_ptr(),
+                                            dV.data_ptr(), self.system._stream()), "ac_ilqr_backward_f32")
+        return K, kff, dV
+
+    def forward(self, x0, Xnom, U, K, kff, alphas=None, out=None):
+        """Closed-loop rollouts for every alpha: Xc (H+1, 13, n_alpha*B), Uc (H, 7, n_alpha*B); column a*B + b."""
+        torch = _torch()
+        lib = self.system._sync()
+        alphas = self.alphas if alphas is None else [float(a) for a in alphas]
+        na = len(alphas)
+        H, B = U.shape[0], U.shape[2]
+        if out is None:
+            out = (torch.empty((H + 1, 13, na * B), device=U.device), torch.empty((H, 7, na * B), device=U.device))
+        Xc, Uc = out
+        arr = (C.c_float * na)(*alphas)
+        _lib.check(lib.ac_rollout_policy_f32(self.system._handle, self._cstruct(), x0.data_ptr(), Xnom.data_ptr(),
+                                             U.data_ptr(), K.data_ptr(), kff.data_ptr(), arr, na, C.c_float(self.dt),
+                                             B, H, Xc.data_ptr(), Uc.data_ptr(), self.system._stream()),
+                   "ac_rollout_policy_f32")
+        return Xc, Uc
+
+    def iterate(self, x0, X, U):
+        """One iLQR iteration in place on (X, U).  Returns (cost (B,), improved (B,) bool)."""
+        torch = _torch()
+        B = U.shape[2]
+        ws = self._workspace(B, U.device)
+        na = len(self.alphas)
+        self.linearise(X, U, want_c=False, out=(ws["F"], ws["A"], ws["Bm"], None))
+        self.backward(X, U, ws["A"], ws["Bm"], out=(ws["K"], ws["kff"], ws["dV"]))
+        self.forward(x0, X, U, ws["K"], ws["kff"], out=(ws["Xc"], ws["Uc"]))
+        self.trajectory_cost(ws["Xc"], ws["Uc"], out=ws["Jc"])
+        self.trajectory_cost(X, U, out=ws["J0"])
+        Jc = ws["Jc"].view(na, B)
+        Jc = torch.where(torch.isfinite(Jc), Jc, torch.full_like(Jc, float("inf")))
+        best, idx = Jc.min(dim=0)
+        improved = best < ws["J0"]
+        col = idx * B + torch.arange(B, device=U.device)
+        Xn = ws["Xc"].index_select(2, col)
+        Un = ws["Uc"].index_select(2, col)
+        X.copy_(torch.where(improved[None, None, :], Xn, X))
+        U.copy_(torch.where(improved[None, None, :], Un, U))
+        return torch.where(improved, best, ws["J0"]), improved
+
+    def solve(self, x0, U0, iters: int = 10):
+        """Rollout from x0 with U0, then `iters` iLQR iterations.  Returns (X, U, cost history (iters+1, B))."""
+        torch = _torch()
+        U = U0.clone()
+        X = self.rollout(x0, U)
+        hist = [self.trajectory_cost(X, U).clone()]
+        for _ in range(iters):
+            J, _ = self.iterate(x0, X, U)
+            hist.append(J.clone())
+        return X, U, torch.stack(hist)

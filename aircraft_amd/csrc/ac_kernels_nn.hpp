@@ -7,6 +7,7 @@
 #pragma once
 #include "ac_kernels_analytic.hpp"
 #include "ac_mlp.hpp"
+#include "ac_ilqr.hpp"
 
 namespace ac {
 
@@ -168,6 +169,50 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_rollout_coop(const DevParams P
         }
 #pragma unroll
         for (int r = 0; r < 7; ++r) u[r] = un[r];
+    }
+    eng.drain();
+}
+
+// Closed-loop (feedback policy) rollout through the MLP surrogate: the cooperative engine, with the control of every
+// node computed from the iLQR gains.  Output instance o = a * B + b (a = line-search index).
+template <int WT, bool USE_MFMA>
+__global__ __launch_bounds__(kBlock, 1) void k_nn_rollout_policy_coop(const DevParams P, const MlpPlan plan,
+                                                                      const float* __restrict__ blob, const Policy pol,
+                                                                      const float* __restrict__ X0, float dt,
+                                                                      long Bout, long H, float* __restrict__ Xout,
+                                                                      float* __restrict__ Uout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MlpEngineCoop<WT, USE_MFMA> eng(plan, blob, smem);
+    eng.load_weights();
+    const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const long raw = (long)blockIdx.x * 16 + col;
+    const bool live = raw < Bout;
+    const long o = live ? raw : Bout - 1;
+    float x[13], u[7];
+    load_rows<13>(X0, pol.B, o % pol.B, x);
+    const bool writer = live && g == 0 && wave == 0;
+    double xa[13];
+#pragma unroll
+    for (int r = 0; r < 13; ++r) xa[r] = (double)x[r];
+    if (writer) {
+#pragma unroll
+        for (int r = 0; r < 13; ++r) Xout[(long)r * Bout + o] = x[r];
+    }
+    MlpCoeffs<MlpEngineCoop<WT, USE_MFMA>> coeffs(eng);
+    for (long k = 0; k < H; ++k) {
+#pragma unroll
+        for (int r = 0; r < 13; ++r) x[r] = (float)xa[r];
+        pol.control(k, o, x, u);
+        if (writer) {
+#pragma unroll
+            for (int r = 0; r < 7; ++r) Uout[(k * 7 + r) * Bout + o] = u[r];
+        }
+        state_update_carry(P, coeffs, xa, u, dt);
+        if (writer) {
+            float* out = Xout + (k + 1) * 13 * Bout;
+#pragma unroll
+            for (int r = 0; r < 13; ++r) out[(long)r * Bout + o] = (float)xa[r];
+        }
     }
     eng.drain();
 }

@@ -10,6 +10,7 @@
 
 #include "ac_kernels_analytic.hpp"
 #include "ac_nn_decl.hpp"
+#include "ac_ilqr.hpp"
 
 using namespace ac;
 
@@ -447,6 +448,87 @@ int ac_traj_cost_f32(ac_handle* h, const float* X, long B, long H, const float* 
     const int grid = (int)((B + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_traj_cost, grid, kBlock, 0, st, X, B, H, goal3[0], goal3[1], goal3[2], w_track, w_goal, cost);
     note_launch(h, "k_traj_cost", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+static IlqrCost to_dev_cost(const ac_ilqr_cost* c) {
+    IlqrCost d;
+    static_assert(sizeof(IlqrCost) == sizeof(ac_ilqr_cost), "ac_ilqr_cost layout");
+    memcpy(&d, c, sizeof(d));
+    return d;
+}
+
+int ac_ilqr_backward_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* X, const float* U, const float* A,
+                         const float* Bm, long B, long H, float* K, float* kff, float* dV, void* stream) {
+    if (h && B == 0) return AC_OK;
+    if (!h || !cost || !X || !U || !A || !Bm || !K || !kff || !dV || B < 0 || H < 1) return AC_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)((B + 3) / 4);
+    hipLaunchKernelGGL(k_ilqr_backward<0>, grid, 64, 0, st, to_dev_cost(cost), X, U, A, Bm, B, H, K, kff, dV);
+    note_launch(h, "k_ilqr_backward", grid, 64, 4 * kIlqrFloats * 4);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_ilqr_cost_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* X, const float* U, long B, long H, float* out,
+                     void* stream) {
+    if (h && B == 0) return AC_OK;
+    if (!h || !cost || !X || !U || !out || B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)((B + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_ilqr_cost<0>, grid, kBlock, 0, st, to_dev_cost(cost), X, U, B, H, out);
+    note_launch(h, "k_ilqr_cost", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_rollout_policy_f32(ac_handle* h, const ac_ilqr_cost* limits, const float* X0, const float* Xnom, const float* U,
+                          const float* K, const float* kff, const float* alphas, int n_alpha, float dt, long B, long H,
+                          float* Xout, float* Uout, void* stream) {
+    if (h && B == 0) return AC_OK;
+    if (!h || !limits || !X0 || !Xnom || !U || !K || !kff || !alphas || !Xout || !Uout || B < 0 || H < 1) return AC_ERR_BAD_ARG;
+    if (n_alpha < 1 || n_alpha > 8) return AC_ERR_BAD_ARG;
+    int rc = model_ready(h);
+    if (rc != AC_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    Policy pol;
+    pol.Xnom = Xnom; pol.U = U; pol.K = K; pol.kff = kff; pol.B = B;
+    pol.alphas.n = n_alpha;
+    for (int i = 0; i < 8; ++i) pol.alphas.a[i] = i < n_alpha ? alphas[i] : 0.f;
+    memcpy(pol.u_min, limits->u_min, sizeof(pol.u_min));
+    memcpy(pol.u_max, limits->u_max, sizeof(pol.u_max));
+    const long Bout = B * n_alpha;
+    if (h->dp.p.model_kind == AC_MODEL_NN) {
+        if (!h->use_mfma) {
+            snprintf(g_err, sizeof(g_err), "policy rollout through the MLP needs the MFMA path");
+            return AC_ERR_UNSUPPORTED;
+        }
+        const int grid = (int)((Bout + 15) / 16);
+        const int lds = h->plan.lds_total + h->wt * 1024;
+        bool launched = false;
+#define AC_POL_CASE(WT_)                                                                                        \
+        if (h->wt == WT_) {                                                                                     \
+            auto kern = k_nn_rollout_policy_coop<WT_, true>;                                                    \
+            int rc_ = set_lds_limit(kern, lds);                                                                 \
+            if (rc_ != AC_OK) return rc_;                                                                       \
+            hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->plan, h->d_blob, pol, X0, dt, Bout, H, Xout, Uout); \
+            launched = true;                                                                                    \
+        }
+        AC_POL_CASE(2) AC_POL_CASE(4) AC_POL_CASE(8)
+#undef AC_POL_CASE
+        if (!launched) return AC_ERR_UNSUPPORTED;
+        note_launch(h, "k_nn_rollout_policy_coop", grid, kBlock, lds);
+        AC_HIP(hipGetLastError());
+        return AC_OK;
+    }
+    const int grid = (int)((Bout + 63) / 64);
+    switch (h->dp.p.model_kind) {
+        case AC_MODEL_LINEAR: hipLaunchKernelGGL(k_rollout_policy<AC_MODEL_LINEAR>, grid, 64, 0, st, h->dp, pol, X0, dt, Bout, H, Xout, Uout); break;
+        case AC_MODEL_POLY: hipLaunchKernelGGL(k_rollout_policy<AC_MODEL_POLY>, grid, 64, 0, st, h->dp, pol, X0, dt, Bout, H, Xout, Uout); break;
+        default: hipLaunchKernelGGL(k_rollout_policy<AC_MODEL_DEFAULT>, grid, 64, 0, st, h->dp, pol, X0, dt, Bout, H, Xout, Uout); break;
+    }
+    note_launch(h, "k_rollout_policy", grid, 64, 0);
     AC_HIP(hipGetLastError());
     return AC_OK;
 }

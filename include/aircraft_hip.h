@@ -133,6 +133,31 @@ int ac_aero_f32(ac_handle* h, const float* X, const float* U, long n, float* out
 int ac_traj_cost_f32(ac_handle* h, const float* X, long B, long H, const float* goal3, float w_track, float w_goal,
                      float* cost, void* stream);
 
+/* ---- batched iLQR / Gauss-Newton sweep on (F, A, B)  (build-side) ---------------------------
+ * Plays the `loss` and control-limit roles of ControlProblem (control/base.py:323-337, control/aircraft.py:29-41,
+ * main/control/control.py:35-70) for B independent instances; the reference itself hands the NLP to IPOPT.
+ *   J = sum_k 1/2 (x_k - x_ref)' diag(q) (x_k - x_ref) + 1/2 u_k' diag(r) u_k + 1/2 (x_N - x_goal)' diag(qf) (x_N - x_goal) */
+typedef struct ac_ilqr_cost {
+    float q[13], qf[13], r[7];
+    float x_ref[13], x_goal[13];
+    float u_min[7], u_max[7];  /* control box (aileron/elevator/rudder limits, control/aircraft.py:29-41) */
+    float reg;                 /* Levenberg term on Quu */
+} ac_ilqr_cost;
+
+/* Backward (Riccati) pass along X [H+1][13][B], U [H][7][B] with A [H][13][13][B], Bm [H][13][7][B] from
+ * ac_shoot_sens_f32.  Outputs K [H][7][13][B], kff [H][7][B], dV [2][B] (expected-improvement terms). */
+int ac_ilqr_backward_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* X, const float* U, const float* A,
+                         const float* Bm, long B, long H, float* K, float* kff, float* dV, void* stream);
+/* cost[b] of a trajectory batch X [H+1][13][B], U [H][7][B] */
+int ac_ilqr_cost_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* X, const float* U, long B, long H,
+                     float* out, void* stream);
+/* Closed-loop rollout with a parallel line search: output instance o = a*B + b uses step alphas[a] (HOST array,
+ * n_alpha <= 8):  u = clip(U_k[b] + alpha kff_k[b] + K_k[b] (x - Xnom_k[b])),  x+ = F(x, u, dt).
+ * X0 [13][B]; Xout [H+1][13][n_alpha*B]; Uout [H][7][n_alpha*B]. */
+int ac_rollout_policy_f32(ac_handle* h, const ac_ilqr_cost* limits, const float* X0, const float* Xnom,
+                          const float* U, const float* K, const float* kff, const float* alphas, int n_alpha, float dt,
+                          long B, long H, float* Xout, float* Uout, void* stream);
+
 /* Diagnostics */
 const char* ac_last_error(void);     /* thread-local text of the last failing HIP call */
 const char* ac_version(void);

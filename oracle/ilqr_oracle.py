@@ -1,0 +1,58 @@
+"""NumPy float64 restatement of the batched iLQR sweep (TEST INFRASTRUCTURE, NOT PRODUCT).
+
+Checks aircraft_amd/csrc/ac_ilqr.hpp: the backward Riccati pass, the closed-loop (feedback policy) rollout and the
+quadratic cost.  The dynamics inside the policy rollout are the C++ oracle's state_update.  Plain loops over
+instances: meant for small cases."""
+import numpy as np
+
+
+def cost(c, X, U):
+    """X (H+1,13,B), U (H,7,B) -> (B,)"""
+    q, qf, r = np.asarray(c.q), np.asarray(c.qf), np.asarray(c.r)
+    dx = X[:-1] - np.asarray(c.x_ref)[None, :, None]
+    dg = X[-1] - np.asarray(c.x_goal)[:, None]
+    return 0.5 * (q[None, :, None] * dx * dx).sum(axis=(0, 1)) + 0.5 * (r[None, :, None] * U * U).sum(axis=(0, 1)) + \
+        0.5 * (qf[:, None] * dg * dg).sum(axis=0)
+
+
+def backward(c, X, U, A, Bm):
+    """A (H,13,13,B), Bm (H,13,7,B) -> K (H,7,13,B), kff (H,7,B), dV (2,B)"""
+    H, _, B = U.shape
+    q, qf, r = np.asarray(c.q, float), np.asarray(c.qf, float), np.asarray(c.r, float)
+    K = np.zeros((H, 7, 13, B)); kff = np.zeros((H, 7, B)); dV = np.zeros((2, B))
+    for b in range(B):
+        Vx = qf * (X[H, :, b] - np.asarray(c.x_goal)); Vxx = np.diag(qf)
+        for k in range(H - 1, -1, -1):
+            Ak, Bk = A[k, :, :, b], Bm[k, :, :, b]
+            lx = q * (X[k, :, b] - np.asarray(c.x_ref)); lu = r * U[k, :, b]
+            Qx = lx + Ak.T @ Vx; Qu = lu + Bk.T @ Vx
+            Qxx = np.diag(q) + Ak.T @ Vxx @ Ak
+            Qux = Bk.T @ Vxx @ Ak
+            Quu = np.diag(r + c.reg) + Bk.T @ Vxx @ Bk
+            Quu = 0.5 * (Quu + Quu.T)
+            Kk = -np.linalg.solve(Quu, Qux); kk = -np.linalg.solve(Quu, Qu)
+            K[k, :, :, b] = Kk; kff[k, :, b] = kk
+            dV[0, b] += kk @ Qu; dV[1, b] += 0.5 * kk @ Quu @ kk
+            Vx = Qx + Kk.T @ Quu @ kk + Kk.T @ Qu + Qux.T @ kk
+            Vxx = Qxx + Kk.T @ Quu @ Kk + Kk.T @ Qux + Qux.T @ Kk
+            Vxx = 0.5 * (Vxx + Vxx.T)
+    return K, kff, dV
+
+
+def forward(orc, c, x0, Xnom, U, K, kff, alphas, dt):
+    """Closed-loop rollouts: returns Xc (H+1,13,na*B), Uc (H,7,na*B), column a*B+b."""
+    H, _, B = U.shape
+    na = len(alphas)
+    Xc = np.zeros((H + 1, 13, na * B)); Uc = np.zeros((H, 7, na * B))
+    umin, umax = np.asarray(c.u_min, float)[:, None], np.asarray(c.u_max, float)[:, None]
+    for a, al in enumerate(alphas):
+        x = x0.copy(); sl = slice(a * B, (a + 1) * B)
+        Xc[0, :, sl] = x
+        for k in range(H):
+            dx = x - Xnom[k]
+            u = U[k] + al * kff[k] + np.einsum("imb,mb->ib", K[k], dx)
+            u = np.clip(u, umin, umax)
+            Uc[k, :, sl] = u
+            x = orc.state_update(x, u, dt)
+            Xc[k + 1, :, sl] = x
+    return Xc, Uc

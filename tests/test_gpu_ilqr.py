@@ -1,0 +1,91 @@
+"""GPU tests of the batched iLQR sweep against the NumPy float64 restatement in oracle/ilqr_oracle.py."""
+import numpy as np
+import pytest
+
+from tests.helpers import block_rel_err, f32_exact, make_aircraft, make_oracle, near_trim_problem, rel_fro
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, gpu):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(gpu)
+
+
+def setup(gpu, model="poly", hidden=None, B=24, H=30):
+    """B gliders released near trim from the same point, flying roughly along +x; the goal is a point a little to the
+    side of where they would coast to, so the optimal controls are small and the closed loop stays in the envelope."""
+    from aircraft_amd.control import ILQR, QuadraticCost
+    from aircraft_amd.synthetic import quat_from_euler, quat_rotate
+
+    ac = make_aircraft(model, hidden=hidden)
+    T = H * 0.01
+    cost = QuadraticCost.goal((60.0 * T, 0.5), w_goal=1.0, height=-200.0, w_height=1.0, w_lateral_speed=0.5, r=0.5, reg=1.0)
+    cost.q = [0, 0, 1e-2, 0, 0, 0, 0, 0, 0, 0, 0.2, 0.2, 0.2]
+    cost.x_ref = [0, 0, -200.0] + [0] * 10
+    il = ILQR(system=ac, dt=0.01, num_nodes=H, cost=cost, alphas=(1.0, 0.5, 0.1))
+    rng = np.random.default_rng(3)
+    X0 = np.zeros((13, B))
+    X0[2] = -200.0
+    V = rng.uniform(50, 65, B); al = np.deg2rad(rng.uniform(-1, 1, B)); be = np.deg2rad(rng.uniform(-1, 1, B))
+    vb = np.stack([V * np.cos(al) * np.cos(be), V * np.sin(be), V * np.sin(al) * np.cos(be)])
+    q = quat_from_euler(np.deg2rad(rng.uniform(-5, 5, B)), np.deg2rad(rng.uniform(-2, 2, B)), np.deg2rad(rng.uniform(-5, 5, B)))
+    X0[3:6] = quat_rotate(q, vb); X0[6:10] = q; X0[10:13] = rng.normal(0, 0.02, (3, B))
+    U = np.zeros((H, 7, B)); U[:, :3] = rng.normal(0, 0.2, (1, 3, B))
+    return ac, il, cost, f32_exact(X0), f32_exact(U)
+
+
+@pytest.mark.parametrize("model,hidden", [("poly", None), ("nn", (64, 64, 64))])
+def test_backward_pass_matches_numpy(gpu, model, hidden):
+    import ilqr_oracle as io
+
+    ac, il, cost, X0, U = setup(gpu, model, hidden)
+    X = il.rollout(dev(X0, gpu), dev(U, gpu))
+    F, A, Bm, _ = il.linearise(X, dev(U, gpu), want_c=False)
+    K, kff, dV = il.backward(X, dev(U, gpu), A, Bm)
+    Xh = X.cpu().numpy().astype(np.float64); Ah = A.cpu().numpy().astype(np.float64); Bh = Bm.cpu().numpy().astype(np.float64)
+    Kr, kr, dVr = io.backward(cost, Xh, U, Ah, Bh)  # same A, B: isolates the Riccati arithmetic
+    assert rel_fro(K.cpu().numpy(), Kr) < 2e-3
+    assert rel_fro(kff.cpu().numpy(), kr) < 2e-3
+    assert rel_fro(dV.cpu().numpy(), dVr) < 2e-3
+    assert (dV.cpu().numpy()[0] <= 0).all()  # descent direction
+
+
+@pytest.mark.parametrize("model,hidden", [("poly", None), ("nn", (64, 64, 64))])
+def test_policy_rollout_and_cost_match_numpy(gpu, model, hidden):
+    import ilqr_oracle as io
+
+    ac, il, cost, X0, U = setup(gpu, model, hidden, B=20, H=25)
+    Ud = dev(U, gpu)
+    X = il.rollout(dev(X0, gpu), Ud)
+    F, A, Bm, _ = il.linearise(X, Ud, want_c=False)
+    K, kff, dV = il.backward(X, Ud, A, Bm)
+    Xc, Uc = il.forward(dev(X0, gpu), X, Ud, K, kff)
+    f64 = lambda t: t.cpu().numpy().astype(np.float64)  # noqa: E731
+    Xr, Ur = io.forward(make_oracle(ac), cost, X0, f64(X), U, f64(K), f64(kff), il.alphas, 0.01)
+    assert np.isfinite(Xr).all() and np.isfinite(Xc.cpu().numpy()).all()
+    assert np.abs(Uc.cpu().numpy() - Ur).max() < 2e-4  # degrees; gains of O(10) times 1e-6 state differences
+    assert block_rel_err(Xc.cpu().numpy(), Xr) < 1e-5
+    Jc = il.trajectory_cost(Xc, Uc).cpu().numpy()
+    assert np.abs(Jc - io.cost(cost, f64(Xc), f64(Uc))).max() / np.abs(Jc).max() < 1e-5
+    # alpha = 0 reproduces the nominal trajectory (within the control box)
+    X0c, U0c = il.forward(dev(X0, gpu), X, Ud, K, kff, alphas=[0.0])
+    assert block_rel_err(X0c.cpu().numpy(), X.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("model,hidden,B", [("poly", None, 256), ("nn", (128, 128, 128, 128), 128)])
+def test_ilqr_cost_decreases(gpu, model, hidden, B):
+    import torch
+
+    ac, il, cost, X0, U = setup(gpu, model, hidden, B=B, H=50)
+    X, Uo, hist = il.solve(dev(X0, gpu), dev(np.zeros_like(U), gpu), iters=6)
+    h = hist.cpu().numpy()
+    assert np.isfinite(h).all()
+    assert (np.diff(h, axis=0) <= 1e-6 * np.abs(h[:-1]) + 1e-6).all()  # monotone per instance
+    assert (h[-1] < h[0]).mean() > 0.9 and np.median(h[-1] / h[0]) < 0.8  # nearly all improve, typically by > 20 %
+    # the accepted (X, U) pair is dynamically consistent: X is the rollout of U from x0
+    Xchk = il.rollout(dev(X0, gpu), Uo)
+    assert block_rel_err(X.cpu().numpy(), Xchk.cpu().numpy()) < 5e-5
+    lim = torch.tensor(cost.u_max, device=Uo.device)[None, :, None]
+    assert bool((Uo <= lim + 1e-6).all()) and bool((Uo >= torch.tensor(cost.u_min, device=Uo.device)[None, :, None] - 1e-6).all())
