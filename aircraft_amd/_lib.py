@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaircraft_hip.so")
+# AIRCRAFT_HIP_LIB selects another build flavor of the same ABI (the diagnostic libaircraft_hip_diag.so)
+LIB_PATH = os.environ.get("AIRCRAFT_HIP_LIB") or os.path.join(_HERE, "libaircraft_hip.so")
 
 AC_OK = 0
 STATUS_NAMES = {0: "AC_OK", -1: "AC_ERR_BAD_ARG", -2: "AC_ERR_HIP", -3: "AC_ERR_UNSUPPORTED",

@@ -27,7 +27,16 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True, jobs: int | None = None) -> str:
+def build(force: bool = False, verbose: bool = True, jobs: int | None = None, diag: bool = False) -> str:
+    """diag=True builds libaircraft_hip_diag.so with -DAC_STAMPS (in-kernel phase stamps, tools/diag_stamps.py);
+    it is a measurement aid, never loaded by the product path unless AIRCRAFT_HIP_LIB points at it."""
+    global OBJ, OUT
+    obj_dir, out = (OBJ + "_diag", OUT.replace(".so", "_diag.so")) if diag else (OBJ, OUT)
+    cflags = CFLAGS + (["-DAC_STAMPS"] if diag else [])
+    return _build(force, verbose, jobs, obj_dir, out, cflags)
+
+
+def _build(force, verbose, jobs, OBJ, OUT, CFLAGS) -> str:
     os.makedirs(OBJ, exist_ok=True)
     todo = []
     objs = []
@@ -56,4 +65,4 @@ def build(force: bool = False, verbose: bool = True, jobs: int | None = None) ->
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, diag="--diag" in sys.argv)

@@ -17,6 +17,14 @@ struct UnitAddr {
     long q, r, blk;
     AC_DI UnitAddr(long u, long blk_) : q(u / blk_), r(u % blk_), blk(blk_) {}
     AC_DI long off(int rows) const { return q * rows * blk + r; }
+    // A copy the optimiser cannot see through.  Used right before the output stores of the long kernels: hipcc
+    // otherwise hoists all ~80 output addresses (64-bit each) to kernel entry, spills them to scratch, and reloads them
+    // one at a time behind a full s_waitcnt vmcnt(0) in front of every store.
+    AC_DI UnitAddr late() const {
+        UnitAddr u = *this;
+        asm volatile("" : "+v"(u.q), "+v"(u.r));
+        return u;
+    }
 };
 
 template <int ROWS> AC_DI void load_rows(const float* __restrict__ src, const UnitAddr& ua, float out[ROWS]) {
@@ -190,9 +198,10 @@ AC_DI void sens_update(const DevParams& P, Coeffs& coeffs, int g, int col, const
     for (int s = 0; s < ns; ++s) {
         rk4_step_seeded(P, coeffs, g, xv, uv, hv, dh, x);
         if (ns > 1) {
+            const UnitAddr ul = ua.late();  // addresses computed here, not hoisted to kernel entry
             if (s > 0) {
                 Dual<4> told[13], tnew[13];
-                if (live) SensIO::load(g, ua, told, A, Bm, c);
+                if (live) SensIO::load(g, ul, told, A, Bm, c);
                 else {
 #pragma unroll
                     for (int i = 0; i < 13; ++i) told[i] = Dual<4>(0.f);
@@ -222,7 +231,7 @@ AC_DI void sens_update(const DevParams& P, Coeffs& coeffs, int g, int col, const
                     for (int j = 0; j < 4; ++j) x[i].d[j] = tnew[i].d[j];
                 }
             }
-            if (live) SensIO::store(g, ua, x, A, Bm, c, false);
+            if (live) SensIO::store(g, ul, x, A, Bm, c, false);
             __builtin_amdgcn_s_waitcnt(0);  // own stores retired before the next sub-step reads them back
 #pragma unroll
             for (int i = 0; i < 13; ++i) xv[i] = x[i].v;
@@ -251,12 +260,13 @@ __global__ __launch_bounds__(kBlock) void k_step_sens(const DevParams P, const f
     AnalyticCoeffs<MODEL> coeffs;
     sens_update(P, coeffs, g, col, ua, xv, uv, hv, x, A, Bm, c, live);
     if (!live) return;
+    const UnitAddr uo = ua.late();
     if (g == 0) {
-        float* p = Xn + ua.off(13);
+        float* p = Xn + uo.off(13);
 #pragma unroll
         for (int i = 0; i < 13; ++i) p[(long)i * blk] = x[i].v;
     }
-    SensIO::store(g, ua, x, A, Bm, c, true);
+    SensIO::store(g, uo, x, A, Bm, c, true);
 }
 
 }  // namespace ac

@@ -36,7 +36,13 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_step_sens(const DevParams P, c
                                                             float* __restrict__ Bm, float* __restrict__ c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MlpEngine<6, WT, USE_MFMA> eng(plan, blob, smem);
+    eng.st.start();
     eng.load_weights();
+    AC_MARK(eng.st, 0);  // [0] prologue: weights into LDS
+#ifdef AC_STAMPS
+    unsigned long long* stamp_buf = reinterpret_cast<unsigned long long*>(c);
+    c = nullptr;
+#endif
     const WaveUnit w(n, blk);
     float xv[13], uv[7];
     load_rows<13>(X, w.ua, xv);
@@ -46,13 +52,20 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_step_sens(const DevParams P, c
     MlpCoeffs<MlpEngine<6, WT, USE_MFMA>> coeffs(eng);
     sens_update(P, coeffs, w.g, w.col, w.ua, xv, uv, hv, x, A, Bm, c, w.live);
     eng.drain();
-    if (!w.live) return;
-    if (w.g == 0) {
-        float* p = Xn + w.ua.off(13);
+    AC_MARK(eng.st, 7);  // [7] dual aero + rigid body + RK4 combine (everything outside forward())
+    if (w.live) {
+        const UnitAddr uo = w.ua.late();
+        if (w.g == 0) {
+            float* p = Xn + uo.off(13);
 #pragma unroll
-        for (int i = 0; i < 13; ++i) p[(long)i * blk] = x[i].v;
+            for (int i = 0; i < 13; ++i) p[(long)i * blk] = x[i].v;
+        }
+        SensIO::store(w.g, uo, x, A, Bm, c, true);
     }
-    SensIO::store(w.g, w.ua, x, A, Bm, c, true);
+    AC_MARK(eng.st, 8);  // [8] stores
+#ifdef AC_STAMPS
+    eng.st.flush(stamp_buf);
+#endif
 }
 
 template <int WT, bool USE_MFMA, int OP>

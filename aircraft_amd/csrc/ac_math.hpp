@@ -23,6 +23,45 @@ struct Dual {
 
 #define AC_DI __device__ __forceinline__
 
+// ---- in-kernel phase stamps: DIAGNOSTIC build flavor only (-DAC_STAMPS; aircraft_amd/build.py --diag) -----------
+// In the product build AC_MARK() expands to nothing.  In the diagnostic flavor every wave accumulates the shader-clock
+// time between consecutive marks into per-phase sums (wave-uniform, SGPRs) and adds them to a global buffer at the end.
+// The buffer travels through the kernel's optional `c` (dF/ddt) pointer, which the diagnostic kernel does not write.
+#ifdef AC_STAMPS
+struct Stamper {
+    unsigned long long last;
+    unsigned long long acc[12];
+    __device__ __forceinline__ void start() {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc[i] = 0;
+        last = __builtin_amdgcn_s_memtime();
+    }
+    __device__ __forceinline__ void mark(int id) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the time value has arrived
+        acc[id] += t - last;
+        last = t;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void flush(unsigned long long* buf) {
+        if ((threadIdx.x & 63) == 0 && buf) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) atomicAdd(&buf[i], acc[i]);
+            atomicAdd(&buf[12], 1ull);
+        }
+    }
+};
+#define AC_MARK(st, id) (st).mark(id)
+#else
+struct Stamper {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(unsigned long long*) {}
+};
+#define AC_MARK(st, id) ((void)0)
+#endif
+
 template <int N> AC_DI Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) {
     Dual<N> r; r.v = a.v + b.v;
 #pragma unroll

@@ -92,6 +92,7 @@ struct MlpEngine {
     char* lds;
     int lane, g, wave, nwaves;
     int ring_pos;  // number of streamed layers consumed so far (slot = ring_pos & 1)
+    Stamper st;    // diagnostic flavor only (empty otherwise)
 
     AC_DI MlpEngine(const MlpPlan& pl, const float* blob, char* lds_base)
         : plan(pl), gblob(blob), lds(lds_base), ring_pos(0) {
@@ -135,12 +136,13 @@ struct MlpEngine {
     }
 
     // CNT output tiles (independent accumulators) x KT k-tiles for slab s; straight-line code, the next
-    // k-tile's A fragments are fetched (ds_read_b128) while the current one's MFMAs issue.  The epilogue of
+    // block's A fragments are fetched (ds_read_b128) while the current one's MFMAs issue.  The epilogue of
     // the PREVIOUS slab (VALU / transcendental work, independent of this slab's MFMAs) is spread over the
     // k-tile blocks so it issues in the shadow of the matrix pipe instead of after it.
     template <int CNT, int KT, int NT>
     AC_DI void gemm_chunk(const f32x4* __restrict__ wf, const f32x4* __restrict__ bias4, int s, int nc, f32x4 (&o)[NT],
-                          const float (&in)[WT][4], const f32x4 (&oprev)[NT], int act) {
+                          const float (&in)[WT][4], const f32x4 (&oprev)[NT], int act, f32x4 (&wcur)[CNT],
+                          bool prefetch_next_chunk) {
         // The chunks of a layer are mutually independent; without a fence the machine scheduler interleaves
         // them across the whole straight-line layer and the live accumulators no longer fit the register file.
         __builtin_amdgcn_sched_barrier(0);
@@ -151,20 +153,28 @@ struct MlpEngine {
             if (s == 0) acc[i] = bias4[(nc + i) * 4 + g];  // value slab starts from the bias
             else acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        f32x4 wcur[CNT], wnext[CNT];
-#pragma unroll
-        for (int i = 0; i < CNT; ++i) wcur[i] = wf[((nc + i) * KT + 0) * 64];
+        f32x4 wnext[CNT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            if (kt + 1 < KT) {
+            const bool last = (kt + 1 == KT);
+            const bool fetch = !last || prefetch_next_chunk;
+            // k-step 0 first: its operands force the wait for THIS block's fragments while no newer LDS read is
+            // outstanding (LDS returns in order; issued the other way round hipcc waits lgkmcnt(0) on the brand-new
+            // reads as well, one exposed LDS latency per block with the matrix pipe idle).
 #pragma unroll
-                for (int i = 0; i < CNT; ++i) wnext[i] = wf[((nc + i) * KT + kt + 1) * 64];
-                // pin the fetch of the NEXT k-tile's fragments ahead of this k-tile's MFMAs (hipcc otherwise sinks
-                // the ds_reads to just before their use and waits lgkmcnt(0) with the matrix pipe idle)
+            for (int i = 0; i < CNT; ++i) acc[i] = mma_16x16x4<USE_MFMA>(wcur[i][0], in[kt][0], acc[i]);
+            if (fetch) {
+                // then fetch the NEXT block's A fragments (next k-tile, or k-tile 0 of the next chunk — they depend on
+                // the output tiles only, not on the slab); 12 MFMAs (384 cycles) cover their latency.
+                __builtin_amdgcn_sched_barrier(0);
+                const int nnc = last ? (nc + CNT) % NT : nc;
+                const int nkt = last ? 0 : kt + 1;
+#pragma unroll
+                for (int i = 0; i < CNT; ++i) wnext[i] = wf[((nnc + i) * KT + nkt) * 64];
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 1; r < 4; ++r)
 #pragma unroll
                 for (int i = 0; i < CNT; ++i) acc[i] = mma_16x16x4<USE_MFMA>(wcur[i][r], in[kt][r], acc[i]);
             if (s > 0) {  // previous slab's epilogue tiles assigned to this block
@@ -173,7 +183,7 @@ struct MlpEngine {
                 for (int t = 0; t < NT; ++t)
                     if (t * kBlocks / NT == blk) epilogue_tile<NT>(s - 1, t, oprev, act);
             }
-            if (kt + 1 < KT) {
+            if (fetch) {
 #pragma unroll
                 for (int i = 0; i < CNT; ++i) wcur[i] = wnext[i];
             }
@@ -193,14 +203,54 @@ struct MlpEngine {
         constexpr int C = NT < CH ? NT : CH;
         static_assert(NT % C == 0, "tile count must be a multiple of the chunk");
         f32x4 o[2][NT];  // ping-pong: slab s accumulates into o[s&1] while slab s-1's epilogue drains o[(s-1)&1]
+        f32x4 wcur[C];   // A fragments of the block about to run; carried across chunks
+#pragma unroll
+        for (int i = 0; i < C; ++i) wcur[i] = wf[(i * KT + 0) * 64];
 #pragma unroll
         for (int s = 0; s < NSLAB; ++s) {
 #pragma unroll
-            for (int nc = 0; nc < NT; nc += C)
-                gemm_chunk<C, KT, NT>(wf, bias4, s, nc, o[s & 1], a[s], o[(s + 1) & 1], act);
+            for (int nc = 0; nc < NT; nc += C) {
+                const bool more = !(s == NSLAB - 1 && nc + C >= NT);
+                gemm_chunk<C, KT, NT>(wf, bias4, s, nc, o[s & 1], a[s], o[(s + 1) & 1], act, wcur, more);
+            }
+            if (KT == WT && NT == WT) { if (s == 0) AC_MARK(st, 9); else if (s == 1) AC_MARK(st, 10); else AC_MARK(st, 11); }
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) epilogue_tile<NT>(NSLAB - 1, nt, o[(NSLAB - 1) & 1], act);
+    }
+
+    // First layer (5 -> width), tangent-aware: the value slab runs on the MFMA (one padded k-tile); the tangent
+    // slabs of the first layer are just columns of W0 scaled by act'(h) — W0[n][j] (1 - h_n^2) — so they are read
+    // from a transposed copy of W0 the host appends to the block, with no MFMA at all (saves 5/6 of this layer's
+    // matrix work, 3 % of a stage).
+    AC_DI void layer_first(const char* wl, int act) {
+        const f32x4* wf = reinterpret_cast<const f32x4*>(wl) + lane;
+        const f32x4* bias4 = reinterpret_cast<const f32x4*>(wl + WT * 1024);
+        const f32x4* w0t = reinterpret_cast<const f32x4*>(wl + WT * 1024 + 1024);  // [5][16*WT] floats
+        f32x4 o[WT];
+#pragma unroll
+        for (int nt = 0; nt < WT; ++nt) {
+            f32x4 acc = bias4[nt * 4 + g];
+            const f32x4 w = wf[nt * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = mma_16x16x4<USE_MFMA>(w[r], a[0][0][r], acc);
+            o[nt] = acc;
+        }
+#pragma unroll
+        for (int nt = 0; nt < WT; ++nt) epilogue_tile<WT>(0, nt, o, act);
+        if constexpr (kTangent) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int nt = 0; nt < WT; ++nt) {
+                    const f32x4 w = w0t[j * (WT * 4) + 4 * nt + g];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float h = a[0][nt][r];
+                        a[1 + j][nt][r] = act ? w[r] * fmaf(-h, h, 1.0f) : w[r];
+                    }
+                }
+        }
     }
 
     // LDS address of layer l's block; for a streamed layer: wait for its DMA, then (the barrier having
@@ -235,13 +285,21 @@ struct MlpEngine {
             }
         }
         const int L = plan.n_layers;
+        AC_MARK(st, 1);  // [1] primal aero + input slab
         if (L == 1) {
             layer<1, 1>(acquire(0), plan.act[0]);
         } else {
-            layer<1, WT>(acquire(0), plan.act[0]);
+            layer_first(acquire(0), plan.act[0]);
+            AC_MARK(st, 2);  // [2] first layer
 #pragma nounroll
-            for (int l = 1; l < L - 1; ++l) layer<WT, WT>(acquire(l), plan.act[l]);
+            for (int l = 1; l < L - 1; ++l) {
+                const char* wl = acquire(l);
+                AC_MARK(st, 3);  // [3] acquire: DMA wait + barrier + DMA issue
+                layer<WT, WT>(wl, plan.act[l]);
+                AC_MARK(st, 4);  // [4] hidden layer GEMM + epilogues
+            }
             layer<WT, 1>(acquire(L - 1), plan.act[L - 1]);
+            AC_MARK(st, 5);  // [5] last layer
         }
         // outputs: rows 0..5 of tile 0 — row k sits in register k&3 of lane (col, k>>2)
         const int col = lane & 15;
@@ -254,6 +312,7 @@ struct MlpEngine {
                 for (int j = 0; j < 5; ++j) J[k][j] = __shfl(a[1 + j][0][k & 3], src, 64);
             }
         }
+        AC_MARK(st, 6);  // [6] output broadcast
     }
 };
 

@@ -209,6 +209,8 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
         pl.NT[l] = (l == n_layers - 1) ? 1 : wt;
         pl.act[l] = act[l] ? 1 : 0;
         pl.bytes[l] = pl.NT[l] * pl.KT[l] * 1024 + 1024;  // weights + one 1-KiB bias piece (whole LDS-DMA pieces only)
+        // first layer of a multi-layer net: + W0 transposed [5][16*wt] for the MFMA-free tangent slabs
+        if (l == 0 && n_layers > 1) pl.bytes[l] += ((5 * wt * 64 + 1023) / 1024) * 1024;
         pl.g_off[l] = (int)total_floats;
         total_floats += (size_t)pl.bytes[l] / 4;
     }
@@ -227,6 +229,11 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
                     }
         float* bd = dst + (size_t)NT * KT * 256;
         for (int i = 0; i < NT * 16; ++i) bd[i] = i < nout ? b[l][i] : 0.f;
+        if (l == 0 && n_layers > 1) {
+            float* wt0 = bd + 256;  // after the 1-KiB bias piece
+            for (int j = 0; j < 5; ++j)
+                for (int n = 0; n < wt * 16; ++n) wt0[j * wt * 16 + n] = n < nout ? W[l][(size_t)n * nin + j] : 0.f;
+        }
     }
     // LDS plan: everything resident if it fits; otherwise the largest layers stream through a 2-slot ring.
     {
