@@ -147,14 +147,12 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_rollout(const DevParams P, con
 
 // Cooperative rollout: one 4-wave workgroup per 16 instances (see MlpEngineCoop).  Every wave integrates the same
 // 16 instances (the rigid-body part is tiny); wave 0 writes the trajectory.
-template <int WT, bool USE_MFMA>
-__global__ __launch_bounds__(kBlock, 1) void k_nn_rollout_coop(const DevParams P, const MlpPlan plan,
-                                                               const float* __restrict__ blob,
-                                                               const float* __restrict__ X0,
-                                                               const float* __restrict__ U, float dt, long B, long H,
-                                                               float* __restrict__ Xout) {
+template <class Engine>
+AC_DI void rollout_coop_body(const DevParams& P, const MlpPlan& plan, const float* __restrict__ blob,
+                             const float* __restrict__ X0, const float* __restrict__ U, float dt, long B, long H,
+                             float* __restrict__ Xout) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    MlpEngineCoop<WT, USE_MFMA> eng(plan, blob, smem);
+    Engine eng(plan, blob, smem);
     eng.load_weights();
     const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
     const long raw = (long)blockIdx.x * 16 + col;
@@ -171,7 +169,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_rollout_coop(const DevParams P
         for (int r = 0; r < 13; ++r) Xout[(long)r * B + unit] = x[r];
     }
     if (H > 0) load_rows<7>(U, B, unit, u);
-    MlpCoeffs<MlpEngineCoop<WT, USE_MFMA>> coeffs(eng);
+    MlpCoeffs<Engine> coeffs(eng);
     for (long k = 0; k < H; ++k) {
         if (k + 1 < H) load_rows<7>(U + (k + 1) * 7 * B, B, unit, un);
         state_update_carry(P, coeffs, xa, u, dt);
@@ -186,16 +184,33 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_rollout_coop(const DevParams P
     eng.drain();
 }
 
+template <int WT, bool USE_MFMA>
+__global__ __launch_bounds__(kBlock, 1) void k_nn_rollout_coop(const DevParams P, const MlpPlan plan,
+                                                               const float* __restrict__ blob,
+                                                               const float* __restrict__ X0,
+                                                               const float* __restrict__ U, float dt, long B, long H,
+                                                               float* __restrict__ Xout) {
+    rollout_coop_body<MlpEngineCoop<WT, USE_MFMA>>(P, plan, blob, X0, U, dt, B, H, Xout);
+}
+
+// Same, weights resident in registers for the whole horizon (NH hidden layers; see MlpEngineCoopReg).
+template <int WT, int NH>
+__global__ __launch_bounds__(kBlock, 1) void k_nn_rollout_reg(const DevParams P, const MlpPlan plan,
+                                                              const float* __restrict__ blob,
+                                                              const float* __restrict__ X0,
+                                                              const float* __restrict__ U, float dt, long B, long H,
+                                                              float* __restrict__ Xout) {
+    rollout_coop_body<MlpEngineCoopReg<WT, NH, true>>(P, plan, blob, X0, U, dt, B, H, Xout);
+}
+
 // Closed-loop (feedback policy) rollout through the MLP surrogate: the cooperative engine, with the control of every
 // node computed from the iLQR gains.  Output instance o = a * B + b (a = line-search index).
-template <int WT, bool USE_MFMA>
-__global__ __launch_bounds__(kBlock, 1) void k_nn_rollout_policy_coop(const DevParams P, const MlpPlan plan,
-                                                                      const float* __restrict__ blob, const Policy pol,
-                                                                      const float* __restrict__ X0, float dt,
-                                                                      long Bout, long H, float* __restrict__ Xout,
-                                                                      float* __restrict__ Uout) {
+template <class Engine>
+AC_DI void rollout_policy_body(const DevParams& P, const MlpPlan& plan, const float* __restrict__ blob,
+                               const Policy& pol, const float* __restrict__ X0, float dt, long Bout, long H,
+                               float* __restrict__ Xout, float* __restrict__ Uout) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    MlpEngineCoop<WT, USE_MFMA> eng(plan, blob, smem);
+    Engine eng(plan, blob, smem);
     eng.load_weights();
     const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
     const long raw = (long)blockIdx.x * 16 + col;
@@ -211,7 +226,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_rollout_policy_coop(const DevP
 #pragma unroll
         for (int r = 0; r < 13; ++r) Xout[(long)r * Bout + o] = x[r];
     }
-    MlpCoeffs<MlpEngineCoop<WT, USE_MFMA>> coeffs(eng);
+    MlpCoeffs<Engine> coeffs(eng);
     for (long k = 0; k < H; ++k) {
 #pragma unroll
         for (int r = 0; r < 13; ++r) x[r] = (float)xa[r];
@@ -228,6 +243,24 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_rollout_policy_coop(const DevP
         }
     }
     eng.drain();
+}
+
+template <int WT, bool USE_MFMA>
+__global__ __launch_bounds__(kBlock, 1) void k_nn_rollout_policy_coop(const DevParams P, const MlpPlan plan,
+                                                                      const float* __restrict__ blob, const Policy pol,
+                                                                      const float* __restrict__ X0, float dt,
+                                                                      long Bout, long H, float* __restrict__ Xout,
+                                                                      float* __restrict__ Uout) {
+    rollout_policy_body<MlpEngineCoop<WT, USE_MFMA>>(P, plan, blob, pol, X0, dt, Bout, H, Xout, Uout);
+}
+
+template <int WT, int NH>
+__global__ __launch_bounds__(kBlock, 1) void k_nn_rollout_policy_reg(const DevParams P, const MlpPlan plan,
+                                                                     const float* __restrict__ blob, const Policy pol,
+                                                                     const float* __restrict__ X0, float dt,
+                                                                     long Bout, long H, float* __restrict__ Xout,
+                                                                     float* __restrict__ Uout) {
+    rollout_policy_body<MlpEngineCoopReg<WT, NH, true>>(P, plan, blob, pol, X0, dt, Bout, H, Xout, Uout);
 }
 
 }  // namespace ac

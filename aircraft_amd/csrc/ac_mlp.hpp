@@ -436,6 +436,129 @@ struct MlpEngineCoop {
     }
 };
 
+// ---- cooperative forward engine with REGISTER-RESIDENT weights (rollouts) ------------------------------------
+// In the cooperative split each wave only ever multiplies by the fragments of its OWN output tiles: T = WT/4 tiles x WT
+// k-tiles x 4 floats = 64 registers per 128x128 layer.  A rollout applies the same network H x 4 times, so the wave
+// loads its fragments once and keeps them in registers for the whole horizon: no LDS weight image, no LDS-DMA issue,
+// no ring; LDS only holds the double-buffered activation exchange (one barrier per layer).  NH = number of hidden
+// (width x width) layers; the layer loop is unrolled so the fragment registers are statically indexed.
+template <int WT, int NH, bool USE_MFMA>
+struct MlpEngineCoopReg {
+    static constexpr bool kTangent = false;
+    static constexpr int kWaves = 4;
+    static constexpr int T = WT >= kWaves ? WT / kWaves : 1;  // output tiles per wave
+
+    float a[WT][4];
+    f32x4 w0[T], b0[T];            // first layer: one k-tile
+    f32x4 wh[NH][T][WT], bh[NH][T];
+    f32x4 wl[WT], bl;              // last layer: tile 0, used by wave 0
+    const MlpPlan& plan;
+    f32x4* xbuf;                   // [2][WT tiles][64 lanes]
+    int lane, g, wave, t0, buf;
+    bool active;                   // this wave owns tiles of the wide layers
+
+    AC_DI MlpEngineCoopReg(const MlpPlan& pl, const float* blob, char* lds_base) : plan(pl), buf(0) {
+        lane = threadIdx.x & 63; g = lane >> 4; wave = threadIdx.x >> 6;
+        xbuf = reinterpret_cast<f32x4*>(lds_base);
+        t0 = wave * T;
+        active = t0 < WT;
+        const int tt = active ? t0 : 0;  // idle waves (WT < 4) shadow tile 0 to stay in bounds
+        const f32x4* g0 = reinterpret_cast<const f32x4*>(blob + pl.g_off[0]);
+#pragma unroll
+        for (int i = 0; i < T; ++i) { w0[i] = g0[(tt + i) * 64 + lane]; b0[i] = g0[WT * 64 + (tt + i) * 4 + g]; }
+#pragma unroll
+        for (int l = 0; l < NH; ++l) {
+            const f32x4* gl = reinterpret_cast<const f32x4*>(blob + pl.g_off[1 + l]);
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+#pragma unroll
+                for (int kt = 0; kt < WT; ++kt) wh[l][i][kt] = gl[((tt + i) * WT + kt) * 64 + lane];
+                bh[l][i] = gl[WT * WT * 64 + (tt + i) * 4 + g];
+            }
+        }
+        const f32x4* gL = reinterpret_cast<const f32x4*>(blob + pl.g_off[1 + NH]);
+#pragma unroll
+        for (int kt = 0; kt < WT; ++kt) wl[kt] = gL[kt * 64 + lane];
+        bl = gL[WT * 64 + g];
+    }
+    AC_DI void load_weights() {}
+    AC_DI void drain() {}
+
+    AC_DI f32x4 activate(f32x4 v, int act) const {
+        f32x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = act ? act_tanh(v[r]) : v[r];
+        return h;
+    }
+    // publish this wave's tiles, one barrier, then every wave pulls the whole slab
+    template <int NTILES> AC_DI void exchange() {
+        __syncthreads();
+        const f32x4* src = xbuf + buf * (WT * 64);
+#pragma unroll
+        for (int t = 0; t < NTILES; ++t) {
+            const f32x4 h = src[t * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[t][r] = h[r];
+        }
+        buf ^= 1;
+    }
+
+    AC_DI void forward(const float z[5], float y[6], float (*)[5]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v = (row == k) ? z[k] : v;
+            a[0][r] = v;
+        }
+        // first layer: 5 (padded 16) -> 16 WT
+        if (active) {
+            f32x4* dst = xbuf + buf * (WT * 64);
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                f32x4 acc = b0[i];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = mma_16x16x4<USE_MFMA>(w0[i][r], a[0][r], acc);
+                dst[(t0 + i) * 64 + lane] = activate(acc, plan.act[0]);
+            }
+        }
+        exchange<WT>();
+        // hidden layers
+#pragma unroll
+        for (int l = 0; l < NH; ++l) {
+            if (active) {
+                f32x4 acc[T];
+#pragma unroll
+                for (int i = 0; i < T; ++i) acc[i] = bh[l][i];
+#pragma unroll
+                for (int kt = 0; kt < WT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int i = 0; i < T; ++i) acc[i] = mma_16x16x4<USE_MFMA>(wh[l][i][kt][r], a[kt][r], acc[i]);
+                f32x4* dst = xbuf + buf * (WT * 64);
+#pragma unroll
+                for (int i = 0; i < T; ++i) dst[(t0 + i) * 64 + lane] = activate(acc[i], plan.act[1 + l]);
+            }
+            exchange<WT>();
+        }
+        // last layer: one output tile, wave 0
+        if (wave == 0) {
+            f32x4 acc = bl;
+#pragma unroll
+            for (int kt = 0; kt < WT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = mma_16x16x4<USE_MFMA>(wl[kt][r], a[kt][r], acc);
+            xbuf[buf * (WT * 64) + lane] = activate(acc, plan.act[1 + NH]);
+        }
+        exchange<1>();
+        const int col = lane & 15;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) y[k] = __shfl(a[0][k & 3], col + 16 * (k >> 2), 64);
+    }
+};
+
 // Coefficient provider that plugs the engine into state_derivative().  prefetch() runs the network on the
 // primal aerodynamic inputs of the stage state and keeps only y[6] (+ J[6][5]); operator() then applies the
 // output scaler and, for duals, the chain rule  dC = J . d(inputs)  — the custom-Jacobian rule l4casadi

@@ -370,6 +370,24 @@ int ac_rollout_f32(ac_handle* h, const float* X0, const float* U, float dt, long
     if (h->dp.p.model_kind == AC_MODEL_NN) {
         const long groups = (B + 15) / 16;  // 16 instances per wave-slab
         bool launched = false;
+        const int nh = h->plan.n_layers - 2;  // hidden (width x width) layers
+        if (h->use_mfma && groups < 4096 && nh >= 1 && nh <= 3) {
+            // cooperative with register-resident weights: each wave keeps the fragments of its own output tiles
+            const int grid = (int)groups;
+            const int lds = 2 * h->wt * 1024;  // double-buffered activation exchange only
+#define AC_REG_CASE(WT_, NH_)                                                                                \
+            if (h->wt == WT_ && nh == NH_) {                                                                \
+                hipLaunchKernelGGL((k_nn_rollout_reg<WT_, NH_>), grid, kBlock, lds, st, h->dp, h->plan, h->d_blob, X0, U, dt, B, H, Xout); \
+                launched = true;                                                                            \
+            }
+            AC_REG_CASE(2, 1) AC_REG_CASE(2, 2) AC_REG_CASE(2, 3) AC_REG_CASE(4, 1) AC_REG_CASE(4, 2) AC_REG_CASE(4, 3)
+            AC_REG_CASE(8, 1) AC_REG_CASE(8, 2) AC_REG_CASE(8, 3)
+#undef AC_REG_CASE
+            if (!launched) return AC_ERR_UNSUPPORTED;
+            note_launch(h, "k_nn_rollout_reg", grid, kBlock, lds);
+            AC_HIP(hipGetLastError());
+            return AC_OK;
+        }
         if (h->use_mfma && groups < 4096) {
             // cooperative: one 4-wave workgroup per 16 instances (4x the parallelism per instance)
             const int grid = (int)groups;
@@ -512,8 +530,24 @@ int ac_rollout_policy_f32(ac_handle* h, const ac_ilqr_cost* limits, const float*
             return AC_ERR_UNSUPPORTED;
         }
         const int grid = (int)((Bout + 15) / 16);
-        const int lds = h->plan.lds_total + h->wt * 1024;
         bool launched = false;
+        const int nh = h->plan.n_layers - 2;
+        if (nh >= 1 && nh <= 3) {
+            const int ldsr = 2 * h->wt * 1024;
+#define AC_POLREG_CASE(WT_, NH_)                                                                                \
+            if (h->wt == WT_ && nh == NH_) {                                                                    \
+                hipLaunchKernelGGL((k_nn_rollout_policy_reg<WT_, NH_>), grid, kBlock, ldsr, st, h->dp, h->plan, h->d_blob, pol, X0, dt, Bout, H, Xout, Uout); \
+                launched = true;                                                                                \
+            }
+            AC_POLREG_CASE(2, 1) AC_POLREG_CASE(2, 2) AC_POLREG_CASE(2, 3) AC_POLREG_CASE(4, 1) AC_POLREG_CASE(4, 2)
+            AC_POLREG_CASE(4, 3) AC_POLREG_CASE(8, 1) AC_POLREG_CASE(8, 2) AC_POLREG_CASE(8, 3)
+#undef AC_POLREG_CASE
+            if (!launched) return AC_ERR_UNSUPPORTED;
+            note_launch(h, "k_nn_rollout_policy_reg", grid, kBlock, ldsr);
+            AC_HIP(hipGetLastError());
+            return AC_OK;
+        }
+        const int lds = h->plan.lds_total + h->wt * 1024;
 #define AC_POL_CASE(WT_)                                                                                        \
         if (h->wt == WT_) {                                                                                     \
             auto kern = k_nn_rollout_policy_coop<WT_, true>;                                                    \
