@@ -89,3 +89,24 @@ def test_ilqr_cost_decreases(gpu, model, hidden, B):
     assert block_rel_err(X.cpu().numpy(), Xchk.cpu().numpy()) < 5e-5
     lim = torch.tensor(cost.u_max, device=Uo.device)[None, :, None]
     assert bool((Uo <= lim + 1e-6).all()) and bool((Uo >= torch.tensor(cost.u_min, device=Uo.device)[None, :, None] - 1e-6).all())
+
+
+def test_receding_horizon_loop_eager_equals_graph(gpu):
+    """The closed loop of main/mhe/mhtt.py:79-124 (solve, keep N-overlap nodes, restart from the last kept state):
+    a hipGraph replay of one cycle reproduces the eager loop bit for bit, and the executed trajectory is continuous."""
+    import torch
+    from aircraft_amd.control import RecedingHorizon
+
+    ac, il, cost, X0, U = setup(gpu, "nn", (64, 64, 64), B=64, H=50)
+    x0, U0 = dev(X0, gpu), dev(np.zeros_like(U), gpu)
+    eager = RecedingHorizon(il, overlap=30, iterations=2).allocate(x0, U0)
+    he = eager.run(4, record=True)
+    graph = RecedingHorizon(il, overlap=30, iterations=2).allocate(x0, U0).capture()
+    hg = graph.run(4, record=True)
+    assert he.shape == (4 * 20 + 1, 13, 64)
+    assert torch.equal(he, hg) and torch.equal(eager.x0, graph.x0) and torch.equal(eager.U, graph.U)
+    assert torch.isfinite(he).all()
+    # continuity: consecutive executed states are one dt apart (positions move by ~v dt, never jump)
+    step = (he[1:, 0:3] - he[:-1, 0:3]).norm(dim=1)
+    speed = he[:-1, 3:6].norm(dim=1)
+    assert float((step - speed * 0.01).abs().max()) < 0.05
