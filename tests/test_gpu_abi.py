@@ -1,0 +1,106 @@
+"""GPU tests of the raw C ABI: status codes, model-data requirements, handles and streams."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.helpers import block_rel_err, f32_exact, make_aircraft, make_oracle, synthetic_units
+
+pytestmark = pytest.mark.gpu
+
+
+def test_status_codes(gpu):
+    import torch
+
+    from aircraft_amd import _lib
+
+    lib = _lib.load()
+    ac = make_aircraft("default")
+    ac._sync()
+    h = ac._handle
+    X = torch.zeros((13, 8), device=gpu); U = torch.zeros((7, 8), device=gpu); out = torch.empty_like(X)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.ac_step_f32(h, X.data_ptr(), U.data_ptr(), C.c_float(0.01), None, 8, out.data_ptr(), st) == 0
+    assert lib.ac_step_f32(h, None, U.data_ptr(), C.c_float(0.01), None, 8, out.data_ptr(), st) == -1
+    assert lib.ac_step_f32(h, X.data_ptr(), U.data_ptr(), C.c_float(0.01), None, -1, out.data_ptr(), st) == -1
+    assert lib.ac_step_f32(None, X.data_ptr(), U.data_ptr(), C.c_float(0.01), None, 8, out.data_ptr(), st) == -1
+    assert lib.ac_step_f32(h, None, None, C.c_float(0.01), None, 0, None, st) == 0  # empty batch is fine
+    assert lib.ac_step_sens_f32(h, X.data_ptr(), U.data_ptr(), C.c_float(0.01), None, 8, out.data_ptr(), None, None, None, st) == -1
+    # a model kind whose data was never supplied
+    p = ac._param_struct()
+    for kind in (1, 2, 3):
+        p.model_kind = kind
+        h2 = C.c_void_p()
+        assert lib.ac_create(C.byref(p), C.byref(h2)) == 0
+        assert lib.ac_step_f32(h2, X.data_ptr(), U.data_ptr(), C.c_float(0.01), None, 8, out.data_ptr(), st) == -4
+        assert lib.ac_destroy(h2) == 0
+    # MLP topology checks
+    h3 = C.c_void_p(); p.model_kind = 2
+    assert lib.ac_create(C.byref(p), C.byref(h3)) == 0
+    fp = C.POINTER(C.c_float)
+    W = np.zeros((6, 4), dtype=np.float32); b = np.zeros(6, dtype=np.float32); sc = np.ones(6, dtype=np.float32)
+    widths = (C.c_int * 2)(4, 6); act = (C.c_int * 1)(0)
+    Wp = (fp * 1)(W.ctypes.data_as(fp)); bp = (fp * 1)(b.ctypes.data_as(fp)); s = sc.ctypes.data_as(fp)
+    assert lib.ac_set_mlp(h3, 1, widths, act, Wp, bp, s, s, s, s, 1) == -1  # input width must be 5
+    assert lib.ac_set_mlp(h3, 9, widths, act, Wp, bp, s, s, s, s, 1) == -1  # too many layers
+    assert lib.ac_destroy(h3) == 0
+    arch = C.create_string_buffer(64)
+    assert lib.ac_device_arch(arch, 64) == 0 and arch.value.startswith(b"gfx950")
+
+
+def test_two_handles_two_streams(gpu):
+    """Handles share no state: two models driven from two streams, interleaved, give what they give alone."""
+    import torch
+
+    a, b = make_aircraft("poly", normalise=True), make_aircraft("nn", hidden=(64, 64, 64), normalise=True)
+    X, U = synthetic_units(3000, seed=31); X = f32_exact(X); U = f32_exact(U)
+    Xd = torch.from_numpy(X).float().to(gpu); Ud = torch.from_numpy(U).float().to(gpu)
+    ra, rb = a.state_update(Xd, Ud, 0.01).clone(), b.state_update(Xd, Ud, 0.01).clone()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            oa = a.state_update(Xd, Ud, 0.01)
+        with torch.cuda.stream(s2):
+            ob = b.state_update(Xd, Ud, 0.01)
+        outs.append((oa, ob))
+    torch.cuda.synchronize()
+    for oa, ob in outs:
+        assert torch.equal(oa, ra) and torch.equal(ob, rb)
+    assert block_rel_err(ra.cpu().numpy(), make_oracle(a).state_update(X, U, 0.01)) < 1e-5
+
+
+def test_single_layer_and_odd_width_networks(gpu):
+    """Engine shapes off the beaten path: a single Linear(5,6) 'network' and hidden widths that are not multiples of 16
+    (zero-padded by the host)."""
+    from aircraft_amd import MlpData
+
+    rng = np.random.default_rng(5)
+    sc = ([1745.4, 3.7e-3, 0.0, 0.0, 7.1e-2], [954.0, 0.116, 0.121, 1.755, 2.84], [-0.116, 0, -0.184, 0, -0.0176, 0],
+          [0.0895, 0.0332, 0.6166, 0.0391, 0.2478, 0.0057])
+    nets = [MlpData([rng.normal(0, 0.3, (6, 5))], [rng.normal(0, 0.1, 6)], [0], *sc),
+            MlpData([rng.normal(0, 0.4, (20, 5)), rng.normal(0, 0.2, (37, 20)), rng.normal(0, 0.2, (6, 37))],
+                    [rng.normal(0, 0.1, 20), rng.normal(0, 0.1, 37), rng.normal(0, 0.1, 6)], [1, 1, 0], *sc),
+            MlpData([rng.normal(0, 0.4, (100, 5)), rng.normal(0, 0.1, (6, 100))], [rng.normal(0, 0.1, 100), rng.normal(0, 0.1, 6)],
+                    [1, 0], *sc)]
+    import torch
+    from tests.helpers import rel_fro
+    from aircraft_amd import Aircraft, AircraftConfiguration, AircraftOpts
+    from aircraft_amd.synthetic import GLIDER
+
+    X, U = synthetic_units(150, seed=37); X = f32_exact(X); U = f32_exact(U)
+    Xd = torch.from_numpy(X).float().to(gpu); Ud = torch.from_numpy(U).float().to(gpu)
+    for net in nets:
+        ac = Aircraft(AircraftOpts(coeff_model_type="nn", coeff_model_path=net, aircraft_config=AircraftConfiguration(dict(GLIDER)),
+                                   physical_integration_substeps=1))
+        ac.normalise = True
+        orc = make_oracle(ac)
+        Xn, A, Bm, c = ac.step_sens(Xd, Ud, 0.01)
+        Xr, Ar, Br, cr = orc.step_sens(X, U, 0.01)
+        assert block_rel_err(Xn.cpu().numpy(), Xr) < 1e-5
+        assert rel_fro(A.cpu().numpy(), Ar) < 1e-4 and rel_fro(Bm.cpu().numpy(), Br) < 1e-4
+        assert block_rel_err(ac.state_update(Xd, Ud, 0.01).cpu().numpy(), Xr) < 1e-5
+        Ur = np.repeat(U[None], 6, axis=0)
+        roll = ac.rollout(Xd, torch.from_numpy(Ur).float().to(gpu), 0.01).cpu().numpy()
+        assert block_rel_err(roll[1], Xr) < 1e-5

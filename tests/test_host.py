@@ -154,3 +154,26 @@ def test_synthetic_inputs_are_in_envelope_and_seeded():
     assert V.min() >= 30 and V.max() <= 80 and (X[2] < 0).all() and np.abs(U[:3]).max() <= 5
     X0, Us = synthetic_problem(16, 50)
     assert X0.shape == (13, 16) and Us.shape == (50, 7, 16) and not Us[:, 3:].any()
+
+
+def test_abi_status_codes_without_gpu():
+    """Argument checking and the no-device status are observable without a GPU (no compute call is made)."""
+    import ctypes as C
+
+    import torch
+
+    from aircraft_amd import _lib
+
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.ac_create(None, C.byref(h)) == -1  # AC_ERR_BAD_ARG
+    p = make_aircraft("default")._param_struct()
+    assert lib.ac_create(C.byref(p), None) == -1
+    bad = make_aircraft("default")._param_struct(); bad.substeps = 0
+    assert lib.ac_create(C.byref(bad), C.byref(h)) == -1
+    bad.substeps = 1; bad.model_kind = 9
+    assert lib.ac_create(C.byref(bad), C.byref(h)) == -1
+    assert lib.ac_destroy(None) == -1
+    if not torch.cuda.is_available():
+        assert lib.ac_create(C.byref(p), C.byref(h)) == -5  # AC_ERR_NO_DEVICE
+        assert b"no HIP device" in lib.ac_last_error()
