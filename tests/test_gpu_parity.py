@@ -274,3 +274,29 @@ def test_edges_and_errors(gpu):
     b = ac2.state_update(dev(X, gpu), dev(U, gpu), 0.01).cpu().numpy()
     assert np.abs(a - b).max() > 1e-6
     assert block_rel_err(b, make_oracle(ac2).state_update(X, U, 0.01)) < STATE_TOL
+
+
+def test_controller_initialise_like_the_reference_driver(gpu):
+    """The exact call of main/control/control.py:158-186: poly model, CoM override, 1 sub-step, quaternion ==
+    'integration', N = 400, dt = 0.01, trim state at 80 m/s, initial guess aileron = 1 deg — Controller.initialise()
+    (control.py:72-93) returns a (13+7, N+1) array whose state rows are the rollout of its control rows."""
+    from aircraft_amd.control import MultipleShooting
+
+    ac = build("poly")
+    ms = MultipleShooting(system=ac, dt=0.01, num_nodes=400, opts={"time": "progress", "quaternion": "integration",
+                                                                   "integration": "explicit"})
+    assert ac.normalise is True
+    trim = np.array([0, 0, -200, 80, 0, 0, 0, 0, 0, 1, 0, -1.79366e-43, 0], dtype=np.float64)
+    guess = ms.initialise(trim)
+    assert guess.shape == (20, 401) and np.all(guess[13] == 1) and not guess[14:].any()
+    U = np.zeros((400, 7, 1)); U[:, 0] = 1.0
+    orc = make_oracle(ac)
+    ref = orc.rollout(f32_exact(trim)[:, None], U, 0.01)[:, :, 0].T
+    assert in_envelope(orc, ref).all()  # 4 s of flight with 1 deg of aileron stays inside the envelope
+    assert block_rel_err(guess[:13], ref) < STATE_TOL
+    # MHTT.initialise (control/moving_horizon.py:203-213): N = 50, zero controls, from the 50 m/s trim (mhtt.py:54-62)
+    ms2 = MultipleShooting(system=ac, dt=0.01, num_nodes=50, opts={"time": "fixed", "quaternion": "integration"})
+    trim50 = trim.copy(); trim50[3] = 50.0
+    g2 = ms2.initialise(trim50, controls=np.zeros((7, 51)))
+    ref2 = orc.rollout(f32_exact(trim50)[:, None], np.zeros((50, 7, 1)), 0.01)[:, :, 0].T
+    assert block_rel_err(g2[:13], ref2) < STATE_TOL
