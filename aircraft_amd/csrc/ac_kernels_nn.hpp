@@ -108,6 +108,52 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_fwd(const DevParams P, const M
     }
 }
 
+// Forward kernels, 64 units per wave: four value slabs share every weight fragment and LDS-DMA piece, and each slab's
+// tanh epilogue issues inside the next slab's MFMA stream (MFMA path only; lane = unit).
+template <int WT, int OP>
+__global__ __launch_bounds__(kBlock, 1) void k_nn_fwd4(const DevParams P, const MlpPlan plan,
+                                                       const float* __restrict__ blob, const float* __restrict__ X,
+                                                       const float* __restrict__ U, float dt,
+                                                       const float* __restrict__ dt_per_unit, long n, long blk,
+                                                       float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef MlpEngine<4, WT, true, false> Engine;
+    Engine eng(plan, blob, smem);
+    eng.load_weights();
+    const long raw = (long)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = raw < n;
+    const long unit = live ? raw : n - 1;  // dead lanes shadow the last unit: the engine is wave/workgroup-collective
+    const UnitAddr ua(unit, blk);
+    float x[13], u[7];
+    load_rows<13>(X, ua, x);
+    load_rows<7>(U, ua, u);
+    MlpCoeffs<Engine> coeffs(eng);
+    if constexpr (OP == OP_DERIV) {
+        float xd[13];
+        coeffs.prefetch(P, x, u);
+        state_derivative<float>(P, coeffs, x, u, xd);
+        eng.drain();
+        if (live) store_rows<13>(out, ua.late(), xd);
+    } else if constexpr (OP == OP_STEP) {
+        const float h = dt_per_unit ? dt_per_unit[unit] : dt;
+        state_update(P, coeffs, x, u, h);
+        eng.drain();
+        if (live) store_rows<13>(out, ua.late(), x);
+    } else {
+        coeffs.prefetch(P, x, u);
+        AeroPre<float> a;
+        aero_pre(P, x, a);
+        float C[6];
+        coeffs(P, a, x, u, C);
+        AeroPost<float> o;
+        aero_post(P, a, u, C, o);
+        eng.drain();
+        const float v[20] = {a.vr[0], a.vr[1], a.vr[2], a.V, a.alpha, a.beta, a.qbar, o.C[0], o.C[1], o.C[2],
+                             o.C[3], o.C[4], o.C[5], o.F[0], o.F[1], o.F[2], o.M[0], o.M[1], o.M[2], 0.f};
+        if (live) store_rows<20>(out, ua.late(), v);
+    }
+}
+
 // Sequential rollout, one wave per 16 instances (launched with 4-wave workgroups).  Used for very large batches
 // and for the VALU validation path; moderate batches take k_nn_rollout_coop below.
 template <int WT, bool USE_MFMA>

@@ -80,10 +80,13 @@ AC_DI void lds_dma_copy(const float* __restrict__ gsrc, char* lds_dst, int bytes
     }
 }
 
-// NSLAB: 1 (values only) or 6 (value + 5 input tangents).  WT: register tiles per slab = max width / 16.
-template <int NSLAB, int WT, bool USE_MFMA>
+// NSLAB slabs of 16 columns each.  TANGENT: slab 0 carries values and slabs 1..5 the five input tangents of the SAME
+// 16 units (NSLAB = 6).  Otherwise every slab is a value slab: NSLAB = 1 (16 units, the four lanes of a unit redundant)
+// or NSLAB = 4 (64 units, lane = unit; slab s = units 16 s .. 16 s + 15).  WT: register tiles per slab = width / 16.
+template <int NSLAB, int WT, bool USE_MFMA, bool TANGENT = (NSLAB == 6)>
 struct MlpEngine {
-    static constexpr bool kTangent = NSLAB > 1;
+    static_assert(!TANGENT || NSLAB == 6, "tangent mode = value + 5 input tangents");
+    static constexpr bool kTangent = TANGENT;
     static constexpr int CH = WT < 4 ? WT : 4;  // output tiles computed together (independent accumulators)
 
     float a[NSLAB][WT][4];
@@ -126,8 +129,8 @@ struct MlpEngine {
     AC_DI void epilogue_tile(int s, int nt, const f32x4 (&o)[NT], int act) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (s == 0) {
-                a[0][nt][r] = act ? act_tanh(o[nt][r]) : o[nt][r];
+            if (s == 0 || !TANGENT) {
+                a[s][nt][r] = act ? act_tanh(o[nt][r]) : o[nt][r];
             } else {
                 const float h = a[0][nt][r];  // already the NEW value activation
                 a[s][nt][r] = act ? o[nt][r] * fmaf(-h, h, 1.0f) : o[nt][r];
@@ -150,7 +153,7 @@ struct MlpEngine {
         f32x4 acc[CNT];
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
-            if (s == 0) acc[i] = bias4[(nc + i) * 4 + g];  // value slab starts from the bias
+            if (s == 0 || !TANGENT) acc[i] = bias4[(nc + i) * 4 + g];  // a value slab starts from the bias
             else acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         f32x4 wnext[CNT];
@@ -227,17 +230,20 @@ struct MlpEngine {
         const f32x4* wf = reinterpret_cast<const f32x4*>(wl) + lane;
         const f32x4* bias4 = reinterpret_cast<const f32x4*>(wl + WT * 1024);
         const f32x4* w0t = reinterpret_cast<const f32x4*>(wl + WT * 1024 + 1024);  // [5][16*WT] floats
-        f32x4 o[WT];
 #pragma unroll
-        for (int nt = 0; nt < WT; ++nt) {
-            f32x4 acc = bias4[nt * 4 + g];
-            const f32x4 w = wf[nt * 64];
+        for (int sv = 0; sv < (TANGENT ? 1 : NSLAB); ++sv) {  // every value slab
+            f32x4 o[WT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc = mma_16x16x4<USE_MFMA>(w[r], a[0][0][r], acc);
-            o[nt] = acc;
+            for (int nt = 0; nt < WT; ++nt) {
+                f32x4 acc = bias4[nt * 4 + g];
+                const f32x4 w = wf[nt * 64];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = mma_16x16x4<USE_MFMA>(w[r], a[sv][0][r], acc);
+                o[nt] = acc;
+            }
+#pragma unroll
+            for (int nt = 0; nt < WT; ++nt) epilogue_tile<WT>(sv, nt, o, act);
         }
-#pragma unroll
-        for (int nt = 0; nt < WT; ++nt) epilogue_tile<WT>(0, nt, o, act);
         if constexpr (kTangent) {
 #pragma unroll
             for (int j = 0; j < 5; ++j)
@@ -271,17 +277,32 @@ struct MlpEngine {
     // Every lane of a unit passes the same z and receives the same outputs.  Wave-collective and,
     // when layers are streamed, workgroup-collective (one barrier per streamed layer).
     AC_DI void forward(const float z[5], float y[6], float (*J)[5]) {
-        // layer-0 input slab: rows 0..4 = z, rest 0 ; tangent slab j = unit vector e_j
+        const int col = lane & 15;
+        if constexpr (!TANGENT && NSLAB > 1) {
+            // multi-value mode: lane = unit.  Slab s needs z of unit 16 s + col in rows 0..4 (row k on lane group k>>2).
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * g + r;
-            float v = 0.f;
+            for (int sl = 0; sl < NSLAB; ++sl) {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) v = (row == k) ? z[k] : v;
-            a[0][0][r] = v;
-            if constexpr (kTangent) {
+                for (int r = 0; r < 4; ++r) a[sl][0][r] = 0.f;
 #pragma unroll
-                for (int j = 0; j < 5; ++j) a[1 + j][0][r] = (row == j) ? 1.f : 0.f;
+                for (int k = 0; k < 5; ++k) {
+                    const float v = __shfl(z[k], col + 16 * sl, 64);
+                    if (g == (k >> 2)) a[sl][0][k & 3] = v;
+                }
+            }
+        } else {
+            // layer-0 input slab: rows 0..4 = z, rest 0 ; tangent slab j = unit vector e_j
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * g + r;
+                float v = 0.f;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) v = (row == k) ? z[k] : v;
+                a[0][0][r] = v;
+                if constexpr (kTangent) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) a[1 + j][0][r] = (row == j) ? 1.f : 0.f;
+                }
             }
         }
         const int L = plan.n_layers;
@@ -302,14 +323,26 @@ struct MlpEngine {
             AC_MARK(st, 5);  // [5] last layer
         }
         // outputs: rows 0..5 of tile 0 — row k sits in register k&3 of lane (col, k>>2)
-        const int col = lane & 15;
+        if constexpr (!TANGENT && NSLAB > 1) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int src = col + 16 * (k >> 2);
-            y[k] = __shfl(a[0][0][k & 3], src, 64);
-            if constexpr (kTangent) {
+            for (int k = 0; k < 6; ++k) {
+                float v = 0.f;
 #pragma unroll
-                for (int j = 0; j < 5; ++j) J[k][j] = __shfl(a[1 + j][0][k & 3], src, 64);
+                for (int sl = 0; sl < NSLAB; ++sl) {
+                    const float t = __shfl(a[sl][0][k & 3], col + 16 * (k >> 2), 64);
+                    v = (g == sl) ? t : v;  // this lane's unit lives in slab g
+                }
+                y[k] = v;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int src = col + 16 * (k >> 2);
+                y[k] = __shfl(a[0][0][k & 3], src, 64);
+                if constexpr (kTangent) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) J[k][j] = __shfl(a[1 + j][0][k & 3], src, 64);
+                }
             }
         }
         AC_MARK(st, 6);  // [6] output broadcast

@@ -284,8 +284,28 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
 // ---- compute entry points ------------------------------------------------------------------------
 static int launch_nn_fwd(ac_handle* h, int op, const float* X, const float* U, float dt, const float* dtp, long n,
                          long blk, float* out, hipStream_t st) {
-    const int grid = (int)((n + 63) / 64);
     bool launched = false;
+    // Four value slabs per wave (k_nn_fwd4) amortise the per-layer fixed costs (measured: a 256-unit workgroup takes
+    // 3.4x the time of a 64-unit one) but quarter the number of workgroups; pick it when whole rounds over the 256 CUs
+    // come out cheaper, i.e. for large n where the tail of the last round does not eat the gain.
+    const long rounds1 = ((n + 63) / 64 + 255) / 256, rounds4 = ((n + 255) / 256 + 255) / 256;
+    if (h->use_mfma && 3.4 * (double)rounds4 < (double)rounds1) {
+        const int grid4 = (int)((n + kBlock - 1) / kBlock);
+#define AC_FWD4_CASE(WT_)                                                                                        \
+        if (h->wt == WT_) {                                                                                      \
+            if (op == OP_DERIV) { AC_NN_CASE(WT_, true, (k_nn_fwd4<WT_, OP_DERIV>), grid4, kBlock, X, U, dt, dtp, n, blk, out) } \
+            else if (op == OP_STEP) { AC_NN_CASE(WT_, true, (k_nn_fwd4<WT_, OP_STEP>), grid4, kBlock, X, U, dt, dtp, n, blk, out) } \
+            else { AC_NN_CASE(WT_, true, (k_nn_fwd4<WT_, OP_AERO>), grid4, kBlock, X, U, dt, dtp, n, blk, out) }    \
+        }
+        AC_FWD4_CASE(2) AC_FWD4_CASE(4) AC_FWD4_CASE(8)
+#undef AC_FWD4_CASE
+        if (!launched) return AC_ERR_UNSUPPORTED;
+        note_launch(h, op == OP_DERIV ? "k_nn_fwd4<deriv>" : (op == OP_STEP ? "k_nn_fwd4<step>" : "k_nn_fwd4<aero>"), grid4,
+                    kBlock, h->plan.lds_total);
+        AC_HIP(hipGetLastError());
+        return AC_OK;
+    }
+    const int grid = (int)((n + 63) / 64);
 #define AC_FWD_OPS(WT_, MF_)                                                                                   \
     if (op == OP_DERIV) { AC_NN_CASE(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_DERIV>), grid, kBlock, X, U, dt, dtp, n, blk, out) } \
     else if (op == OP_STEP) { AC_NN_CASE(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_STEP>), grid, kBlock, X, U, dt, dtp, n, blk, out) } \

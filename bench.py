@@ -147,6 +147,20 @@ def main():
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
+    # reported alongside the headline: forward-only passes of the same units, untimed by the driver
+    def _time(fn, iters=10):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    traj = torch.empty((H + 1, 13, B), device=dev)
+    x0 = X[0].contiguous()
+    fwd_ms = _time(lambda: ms.propagate(X, U, out=F))
+    roll_ms = _time(lambda: ms.rollout(x0, U, out=traj), 5)
+
     # HBM traffic of the dominant kernel from the PMC passes (FETCH_SIZE x2 per the gfx950 guide + WRITE_SIZE, calibrated
     # on a known-byte-count kernel of the same access pattern): collected separately with rocprofv3 --pmc and committed
     # under profiles/; it applies to the default workload only.
@@ -180,6 +194,12 @@ def main():
                          "flops_per_unit": flops_unit, "hbm_bytes_per_unit": bytes_unit,
                          "hbm_achieved_GBs": achieved_gbs, "hbm_frac": achieved_gbs / PEAK_HBM_GBS},
         }
+        res["alongside"] = {
+            "forward_shooting_steps_per_s_per_gpu": B * H / fwd_ms * 1e3, "forward_shooting_ms": fwd_ms,
+            "forward_flops_per_unit": 4 * F_mlp + 1500,
+            "forward_tflops": (4 * F_mlp + 1500) * B * H / (fwd_ms * 1e-3) / 1e12,
+            "rollout_steps_per_s_per_gpu": B * H / roll_ms * 1e3, "rollout_ms": roll_ms,
+            "note": "same units, x+ only: ac_shoot_step_f32 (all nodes independent) and ac_rollout_f32 (sequential in k)"}
         if not args.no_cpu_baseline and world == 1:
             Xs = Xh[:H].transpose(1, 0, 2).reshape(13, H * B)
             Us = Uh.transpose(1, 0, 2).reshape(7, H * B)

@@ -167,3 +167,33 @@ def test_hipgraph_capture_of_the_inner_step(gpu):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(traj[0], X[7]) and not torch.equal(traj[1], ref[0][1])
+
+
+@pytest.mark.parametrize("hidden", [None, (128, 128, 128, 128)])
+def test_forward_64_units_per_wave_path(gpu, hidden):
+    """Large n takes the four-slab forward kernels (lane = unit): step, derivative and getters against the oracle on a
+    sample, and bit-equality with the 16-units-per-wave kernels that smaller batches use."""
+    import torch
+    from tests.helpers import synthetic_units
+
+    ac = make_aircraft("nn", hidden=hidden, normalise=True, stall_scaling=True)
+    n = 300001  # ragged
+    X, U = synthetic_units(n, seed=41, flaps=True); X = f32_exact(X); U = f32_exact(U)
+    Xd = torch.from_numpy(X).float().to(gpu); Ud = torch.from_numpy(U).float().to(gpu)
+    orc = make_oracle(ac)
+    idx = np.random.default_rng(2).integers(0, n, 400); idx[0], idx[1] = 0, n - 1
+    out = ac.state_update(Xd, Ud, 0.01)
+    assert ac.last_launch()[0].startswith("k_nn_fwd4")
+    assert block_rel_err(out.cpu().numpy()[:, idx], orc.state_update(X[:, idx], U[:, idx], 0.01)) < 1e-5
+    small = torch.cat([ac.state_update(Xd[:, i:i + 50000].contiguous(), Ud[:, i:i + 50000].contiguous(), 0.01)
+                       for i in range(0, n, 50000)], dim=1)
+    assert ac.last_launch()[0].startswith("k_nn_fwd<")
+    assert torch.equal(out, small)  # same arithmetic whichever kernel evaluates a unit
+    xd = ac.state_derivative(Xd, Ud).cpu().numpy()
+    assert block_rel_err(xd[:, idx], orc.state_derivative(X[:, idx], U[:, idx])) < 2e-5
+    ref = orc.aero(X[:, idx], U[:, idx])
+    got = ac.coefficients(Xd, Ud).cpu().numpy()[:, idx]
+    assert np.abs(got - ref[7:13]).max() / np.abs(ref[7:13]).max() < 2e-5
+    dt = np.random.default_rng(0).uniform(1e-3, 1e-2, n)
+    out2 = ac.state_update(Xd, Ud, torch.from_numpy(dt).float().to(gpu)).cpu().numpy()
+    assert block_rel_err(out2[:, idx], orc.state_update(X[:, idx], U[:, idx], f32_exact(dt)[idx])) < 1e-5
