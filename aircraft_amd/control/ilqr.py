@@ -16,8 +16,6 @@ import ctypes as C
 from dataclasses import dataclass, field
 from typing import Optional, Sequence
 
-import numpy as np
-
 from .. import _lib
 from .base import MultipleShooting
 

@@ -13,8 +13,6 @@ captured once into a hipGraph (torch.cuda.CUDAGraph) and replayed — BASELINE c
 """
 from __future__ import annotations
 
-from typing import Optional
-
 from .ilqr import ILQR
 
 

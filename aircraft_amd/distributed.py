@@ -8,7 +8,7 @@ collective; the single exchange is one all-gather of every rank's best-K traject
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Tuple
+from typing import Tuple
 
 from . import _lib
 

@@ -9,8 +9,7 @@ arithmetic itself runs in the kernels (aircraft_amd/csrc/ac_dynamics.hpp, ac_mlp
 from __future__ import annotations
 
 import ctypes as C
-from pathlib import Path
-from typing import Any, Callable, Dict, Union
+from typing import Callable, Dict
 
 import numpy as np
 

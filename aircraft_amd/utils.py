@@ -6,9 +6,7 @@ Mirrors the parts of the reference's `aircraft.utils` that the dynamics plugin s
 """
 from __future__ import annotations
 
-import io
 import json
-import os
 import pickle
 from pathlib import Path
 from typing import Union

@@ -16,7 +16,6 @@ Sources (all under /root/reference):
   src/aircraft/surrogates/models.py     ScaledModel is IMPORTED (torch only) to produce
                                         forward values + autograd Jacobians = golden vectors
 """
-import io
 import json
 import os
 import pickle

@@ -1,7 +1,6 @@
 """Shared test helpers: build an `Aircraft` (product) and the matching float64 oracle (checker)."""
 from __future__ import annotations
 
-import json
 import os
 import sys
 

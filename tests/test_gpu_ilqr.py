@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from tests.helpers import block_rel_err, f32_exact, make_aircraft, make_oracle, near_trim_problem, rel_fro
+from tests.helpers import block_rel_err, f32_exact, make_aircraft, make_oracle, rel_fro
 
 pytestmark = pytest.mark.gpu
 

@@ -24,8 +24,6 @@ def test_backward_pass_converges_to_the_discrete_riccati_solution():
 def test_cost_struct_layout_and_goal_helper():
     import ctypes
 
-    from aircraft_amd import _lib
-
     c = QuadraticCost.goal((150.0, 0.0), height=-200.0)
     s = c.struct()
     assert ctypes.sizeof(s) == (13 + 13 + 7 + 13 + 13 + 7 + 7 + 1) * 4

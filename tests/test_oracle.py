@@ -10,7 +10,7 @@
 import numpy as np
 import pytest
 
-from tests.helpers import (GLIDER, block_rel_err, f32_exact, golden, make_aircraft, make_oracle, near_trim_problem,
+from tests.helpers import (GLIDER, block_rel_err, golden, make_aircraft, make_oracle, near_trim_problem,
                            synthetic_units)
 
 

@@ -1,14 +1,13 @@
 #!/usr/bin/env python3
 """Secondary measurements (not the headline): every mode of the hot path on one MI355X.
 Prints one JSON object per line; run on the GPU box."""
-import json, os, sys, time
+import json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from aircraft_amd import Aircraft, AircraftConfiguration, AircraftOpts, MlpData
 from aircraft_amd.control import MultipleShooting
-from aircraft_amd.synthetic import GLIDER, synthetic_controls, synthetic_states
+from aircraft_amd.synthetic import synthetic_controls, synthetic_states
 from tests.helpers import make_aircraft
 
 dev = torch.device("cuda", 0)

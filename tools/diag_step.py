@@ -20,7 +20,6 @@ i = int(np.argmax(np.where(ok, np.abs(out[10:13] - ref[10:13]).max(axis=0) / np.
 np.set_printoptions(precision=9, linewidth=200)
 print("x0 ", X[:, i]); print("u  ", U[:, i]); print("ref", ref[:, i]); print("gpu", out[:, i].astype(np.float64)); print("err", out[:, i] - ref[:, i])
 # substep trace with the oracle using fp32-rounded state each substep (emulates pure fp32 carry)
-from oracle import Oracle
 o1 = make_oracle(make_aircraft(model, substeps=1, normalise=False))
 x = X[:, i:i+1].copy(); xs = x.copy()
 for s in range(ns):
