@@ -41,13 +41,21 @@ template <class T> AC_DI void aero_pre(const DevParams& P, const T x[13], AeroPr
 }
 
 // ---- analytic coefficient models -----------------------------------------------------------
-// 34 monomials of sklearn PolynomialFeatures(3, include_bias=False) over f[0..3]:
-// combinations_with_replacement(range(4), d), d = 1, 2, 3 — built by extension so each costs one multiply.
-template <class T> AC_DI void poly_monomials(const T f[4], T m[34]) {
+// Cubic fits over f[0..3] = (alpha, beta, aileron, elevator) with the 34 monomials of sklearn
+// PolynomialFeatures(3, include_bias=False): combinations_with_replacement(range(4), d), d = 1, 2, 3.
+// The monomials are STREAMED, never stored: nested loops i <= j <= k visit the degree-2 terms (index 4 + ...) and the
+// degree-3 terms (index 14 + ...) in exactly sklearn's lexicographic order, each degree-2 product is built once and
+// extended to its degree-3 terms, and every monomial is accumulated into the NOUT requested fits at once.  (Holding
+// the 34 monomials as duals costs 170 registers per evaluation point and made the sensitivity kernel spill 1 KB/lane.)
+// (For plain floats the monomials are cheap to hold — 34 registers — and building them first leaves the compiler a
+// shorter dependent chain: the forward kernels keep that form.)
+template <int NOUT>
+AC_DI void poly_eval(const DevParams& P, const int (&ks)[NOUT], const float f[4], float out[NOUT]) {
+    float m[34];
     int t = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) m[t++] = f[i];
-    T m2[4][4];
+    float m2[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -58,12 +66,39 @@ template <class T> AC_DI void poly_monomials(const T f[4], T m[34]) {
         for (int j = i; j < 4; ++j)
 #pragma unroll
             for (int k = j; k < 4; ++k) m[t++] = m2[i][j] * f[k];
-}
-template <class T> AC_DI T poly_dot(const DevParams& P, int k, const T m[34]) {
-    T acc = T(P.poly_intercept[k]);
 #pragma unroll
-    for (int t = 0; t < 34; ++t) acc = acc + P.poly_coef[k * 34 + t] * m[t];
-    return acc;
+    for (int o = 0; o < NOUT; ++o) {
+        float acc = P.poly_intercept[ks[o]];
+#pragma unroll
+        for (int q = 0; q < 34; ++q) acc = acc + P.poly_coef[ks[o] * 34 + q] * m[q];
+        out[o] = acc;
+    }
+}
+template <int NOUT, class T>
+AC_DI void poly_eval(const DevParams& P, const int (&ks)[NOUT], const T f[4], T out[NOUT]) {
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) out[o] = T(P.poly_intercept[ks[o]]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) out[o] = out[o] + P.poly_coef[ks[o] * 34 + i] * f[i];
+    int t2 = 4, t3 = 14;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i; j < 4; ++j) {
+            const T m2 = f[i] * f[j];
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) out[o] = out[o] + P.poly_coef[ks[o] * 34 + t2] * m2;
+            ++t2;
+#pragma unroll
+            for (int k = j; k < 4; ++k) {
+                const T m3 = m2 * f[k];
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) out[o] = out[o] + P.poly_coef[ks[o] * 34 + t3] * m3;
+                ++t3;
+            }
+        }
 }
 // P_CZ(alpha, 0, 0, 0): only the pure-alpha monomials survive (terms 0, 4, 14)
 template <class T> AC_DI T poly_cz_alpha_only(const DevParams& P, const T& al) {
@@ -101,23 +136,28 @@ template <int MODEL> struct AnalyticCoeffs {
             const T alpha_r = m_atan2(a.vr[2] + b4 * w[0], ux);
             const T vy = a.vr[1] - arm * w[2];
             const T beta_r = m_asin(vy / m_sqrt(a.vr[0] * a.vr[0] + vy * vy + a.vr[2] * a.vr[2] + eps));
-            T m[34];
             {
                 const T f[4] = {a.alpha, a.beta, da, de};
-                poly_monomials(f, m);
+                const int ks[4] = {0, 1, 2, 3};
+                T r4[4];
+                poly_eval<4>(P, ks, f, r4);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) C[k] = poly_dot(P, k, m);
+                for (int k = 0; k < 4; ++k) C[k] = r4[k];
             }
             C[3] = C[3] + (b4 * 0.5f) * (poly_cz_alpha_only(P, alpha_r) - poly_cz_alpha_only(P, alpha_l));
             {
                 const T f[4] = {alpha_e, a.beta, da, de};
-                poly_monomials(f, m);
-                C[4] = poly_dot(P, 4, m);
+                const int ks[1] = {4};
+                T r1[1];
+                poly_eval<1>(P, ks, f, r1);
+                C[4] = r1[0];
             }
             {
                 const T f[4] = {a.alpha, beta_r, da, de};
-                poly_monomials(f, m);
-                C[5] = poly_dot(P, 5, m) + (0.01f * 6.0f * kDeg) * dr;
+                const int ks[1] = {5};
+                T r1[1];
+                poly_eval<1>(P, ks, f, r1);
+                C[5] = r1[0] + (0.01f * 6.0f * kDeg) * dr;
             }
         } else {  // DefaultModel
             C[0] = -(0.02f + 0.3f * (a.alpha * a.alpha));
@@ -272,35 +312,40 @@ AC_DI void state_update(const DevParams& P, Coeffs& coeffs, float x[13], const f
 // The inputs' tangents are 0/1 SEEDS, so they are never stored: the step keeps only the primal x0, u
 // (20 registers) and rebuilds the seed pattern from the lane's group index where it is needed.  That is
 // 80 registers per lane less than carrying Dual x0 and u through the four stages.
-struct Seeds {
-    static AC_DI Dual<4> state(int g, int i, float v) {  // x0[i] as a dual
-        Dual<4> r; r.v = v;
+// N = tangent directions per lane (16 / N lanes per unit): N = 4 for the MLP kernels (the four lanes are the four row
+// groups of the unit's MFMA column), N = 2 (eight lanes per unit) for the analytic models, whose dual arithmetic then
+// fits half the registers and leaves room for two waves per SIMD.
+template <int N> struct SeedsT {
+    static AC_DI Dual<N> state(int g, int i, float v) {  // x0[i] as a dual
+        Dual<N> r; r.v = v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r.d[j] = (i >= 3 && (i - 3) == 4 * g + j) ? 1.f : 0.f;
+        for (int j = 0; j < N; ++j) r.d[j] = (i >= 3 && (i - 3) == N * g + j) ? 1.f : 0.f;
         return r;
     }
-    static AC_DI void controls(int g, const float uv[7], Dual<4> u[7]) {
+    static AC_DI void controls(int g, const float uv[7], Dual<N> u[7]) {
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             u[i].v = uv[i];
             const int dir = (i < 3) ? 10 + i : (i == 6 ? 13 : -1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) u[i].d[j] = (dir == 4 * g + j) ? 1.f : 0.f;
+            for (int j = 0; j < N; ++j) u[i].d[j] = (dir == N * g + j) ? 1.f : 0.f;
         }
     }
-    static AC_DI Dual<4> step(int g, float hv, float dh_ddt) {  // h = dt/substeps as a dual in the dt direction
-        Dual<4> r; r.v = hv;
+    static AC_DI Dual<N> step(int g, float hv, float dh_ddt) {  // h = dt/substeps as a dual in the dt direction
+        Dual<N> r; r.v = hv;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r.d[j] = (14 == 4 * g + j) ? dh_ddt : 0.f;
+        for (int j = 0; j < N; ++j) r.d[j] = (14 == N * g + j) ? dh_ddt : 0.f;
         return r;
     }
 };
+typedef SeedsT<4> Seeds;
 
-// One RK4 step from primal inputs; xo = F(x0, u, h) with tangents w.r.t. this lane's four directions.
-template <class Coeffs>
+// One RK4 step from primal inputs; xo = F(x0, u, h) with tangents w.r.t. this lane's N directions.
+template <int N, class Coeffs>
 AC_DI void rk4_step_seeded(const DevParams& P, Coeffs& coeffs, int g, const float xv[13], const float uv[7],
-                           float hv, float dh_ddt, Dual<4> xo[13]) {
-    typedef Dual<4> T;
+                           float hv, float dh_ddt, Dual<N> xo[13]) {
+    typedef Dual<N> T;
+    typedef SeedsT<N> Seeds;
     T acc[13], xs[13], k[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) { xs[i] = Seeds::state(g, i, xv[i]); acc[i] = T(0.f); }

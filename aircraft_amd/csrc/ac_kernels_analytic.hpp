@@ -127,9 +127,9 @@ __global__ __launch_bounds__(kBlock) void k_aero(const DevParams P, const float*
     store_rows<20>(out, ua, v);
 }
 
-// ---- sensitivities (direction layout: ac_dynamics.hpp, struct Seeds) ------------------------------
-struct SensIO {
-    // column of this lane's direction j in the output arrays: base pointer + row stride (null = no column)
+// ---- sensitivities (direction layout: ac_dynamics.hpp, struct SeedsT) -----------------------------
+template <int N> struct SensIOT {
+    // column of direction d in the output arrays: base pointer + row stride (null = no column)
     static AC_DI void column(int d, long n, float* Au, float* Bu, float* cu, float*& base, long& stride) {
         if (d < 10) { base = Au + (long)(3 + d) * n; stride = 13 * n; }
         else if (d < 13) { base = Bu + (long)(d - 10) * n; stride = 7 * n; }
@@ -138,17 +138,17 @@ struct SensIO {
         else { base = nullptr; stride = 0; }
     }
 
-    // Store this lane's four tangent columns of the 13 outputs (+ its share of the constant columns).
-    static AC_DI void store(int g, const UnitAddr& ua, const Dual<4> x[13], float* __restrict__ A,
+    // Store this lane's N tangent columns of the 13 outputs (+ its share of the constant columns).
+    static AC_DI void store(int g, const UnitAddr& ua, const Dual<N> x[13], float* __restrict__ A,
                             float* __restrict__ Bm, float* __restrict__ c, bool constants) {
         const long n = ua.blk;  // row stride
         float* Au = A + ua.off(169);
         float* Bu = Bm + ua.off(91);
         float* cu = c ? c + ua.off(13) : nullptr;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < N; ++j) {
             float* base; long stride;
-            column(4 * g + j, n, Au, Bu, cu, base, stride);
+            column(N * g + j, n, Au, Bu, cu, base, stride);
             if (base) {
 #pragma unroll
                 for (int i = 0; i < 13; ++i) base[(long)i * stride] = x[i].d[j];
@@ -164,54 +164,57 @@ struct SensIO {
     }
 
     // Read back the columns this lane stored earlier (sub-step composition only).
-    static AC_DI void load(int g, const UnitAddr& ua, Dual<4> x[13], const float* A, const float* Bm,
+    static AC_DI void load(int g, const UnitAddr& ua, Dual<N> x[13], const float* A, const float* Bm,
                            const float* c) {
         const long n = ua.blk;
         float* Au = const_cast<float*>(A) + ua.off(169);
         float* Bu = const_cast<float*>(Bm) + ua.off(91);
         float* cu = c ? const_cast<float*>(c) + ua.off(13) : nullptr;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < N; ++j) {
             float* base; long stride;
-            column(4 * g + j, n, Au, Bu, cu, base, stride);
+            column(N * g + j, n, Au, Bu, cu, base, stride);
 #pragma unroll
             for (int i = 0; i < 13; ++i) x[i].d[j] = base ? base[(long)i * stride] : 0.f;
         }
     }
 };
+typedef SensIOT<4> SensIO;
 
-// The whole sensitivity step for one unit spread over four lanes (g = 0..3).  Wave-collective when the
-// coefficient provider is (MLP engine) and always for substeps > 1 (cross-lane composition).
+// The whole sensitivity step for one unit spread over 16/N lanes (g = 0 .. 16/N - 1; `col` = unit within the wave,
+// units per wave UPW = 4 N).  Wave-collective when the coefficient provider is (MLP engine) and always for
+// substeps > 1 (cross-lane composition).
 //
 // substeps == 1 (every MPC driver of the reference): one seeded RK4 step, tangents stay in registers.
 // substeps  > 1: each sub-step is seeded on its own (local Jacobian T_s w.r.t. its inputs) and composed with
 // the running total  T <- dF_s/dx . T + dF_s/d(u, dt)  kept in the OUTPUT arrays between sub-steps, so the
 // register footprint of the hot path is not paid for by the rare one.
-template <class Coeffs>
+template <int N, class Coeffs>
 AC_DI void sens_update(const DevParams& P, Coeffs& coeffs, int g, int col, const UnitAddr& ua, float xv[13],
-                       const float uv[7], float dt, Dual<4> x[13], float* __restrict__ A, float* __restrict__ Bm,
+                       const float uv[7], float dt, Dual<N> x[13], float* __restrict__ A, float* __restrict__ Bm,
                        float* __restrict__ c, bool live) {
+    constexpr int UPW = 4 * N;  // units per wave
     const int ns = P.p.substeps < 1 ? 1 : P.p.substeps;
     const float hv = (ns == 1) ? dt : dt / (float)ns;
     const float dh = 1.0f / (float)ns;
 #pragma nounroll
     for (int s = 0; s < ns; ++s) {
-        rk4_step_seeded(P, coeffs, g, xv, uv, hv, dh, x);
+        rk4_step_seeded<N>(P, coeffs, g, xv, uv, hv, dh, x);
         if (ns > 1) {
             const UnitAddr ul = ua.late();  // addresses computed here, not hoisted to kernel entry
             if (s > 0) {
-                Dual<4> told[13], tnew[13];
-                if (live) SensIO::load(g, ul, told, A, Bm, c);
+                Dual<N> told[13], tnew[13];
+                if (live) SensIOT<N>::load(g, ul, told, A, Bm, c);
                 else {
 #pragma unroll
-                    for (int i = 0; i < 13; ++i) told[i] = Dual<4>(0.f);
+                    for (int i = 0; i < 13; ++i) told[i] = Dual<N>(0.f);
                 }
 #pragma unroll
                 for (int i = 0; i < 13; ++i) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < N; ++j) {
                         // direct dependence of this sub-step on (u, dt); state directions chain only
-                        float t = (4 * g + j >= 10) ? x[i].d[j] : 0.f;
+                        float t = (N * g + j >= 10) ? x[i].d[j] : 0.f;
                         if (i < 3) t += told[i].d[j];  // dF_s/dp = [I; 0]
                         tnew[i].d[j] = t;
                     }
@@ -220,18 +223,18 @@ AC_DI void sens_update(const DevParams& P, Coeffs& coeffs, int g, int col, const
                 for (int k = 0; k < 10; ++k) {
 #pragma unroll
                     for (int i = 0; i < 13; ++i) {
-                        const float a_ik = __shfl(x[i].d[k & 3], col + 16 * (k >> 2), 64);  // dF_s[i]/dx[3+k]
+                        const float a_ik = __shfl(x[i].d[k % N], col + UPW * (k / N), 64);  // dF_s[i]/dx[3+k]
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) tnew[i].d[j] = fmaf(a_ik, told[3 + k].d[j], tnew[i].d[j]);
+                        for (int j = 0; j < N; ++j) tnew[i].d[j] = fmaf(a_ik, told[3 + k].d[j], tnew[i].d[j]);
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < 13; ++i) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) x[i].d[j] = tnew[i].d[j];
+                    for (int j = 0; j < N; ++j) x[i].d[j] = tnew[i].d[j];
                 }
             }
-            if (live) SensIO::store(g, ul, x, A, Bm, c, false);
+            if (live) SensIOT<N>::store(g, ul, x, A, Bm, c, false);
             __builtin_amdgcn_s_waitcnt(0);  // own stores retired before the next sub-step reads them back
 #pragma unroll
             for (int i = 0; i < 13; ++i) xv[i] = x[i].v;
@@ -240,15 +243,21 @@ AC_DI void sens_update(const DevParams& P, Coeffs& coeffs, int g, int col, const
     if (P.p.normalise) normalise_q(x);
 }
 
+// Directions per lane for the analytic models (measured on MI355X, B x H = 204 800): the cubic-polynomial model spills
+// 1 KB/lane with four directions per lane and runs 1.9x faster with two (eight lanes per unit); the cheap default and
+// linear models prefer four (less redundant primal work).
+template <int MODEL> struct AnalyticSensN { static constexpr int value = (MODEL == AC_MODEL_POLY) ? 2 : 4; };
 template <int MODEL>
 __global__ __launch_bounds__(kBlock) void k_step_sens(const DevParams P, const float* __restrict__ X,
                                                       const float* __restrict__ U, float dt,
                                                       const float* __restrict__ dt_per_unit, long n, long blk,
                                                       float* __restrict__ Xn, float* __restrict__ A,
                                                       float* __restrict__ Bm, float* __restrict__ c) {
+    constexpr int kAnN = AnalyticSensN<MODEL>::value;
+    constexpr int UPW = 4 * kAnN;  // units per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = lane & 15, g = lane >> 4;
-    const long unit_raw = ((long)blockIdx.x * (kBlock / 64) + wave) * 16 + col;
+    const int col = lane % UPW, g = lane / UPW;
+    const long unit_raw = ((long)blockIdx.x * (kBlock / 64) + wave) * UPW + col;
     const bool live = unit_raw < n;
     const long unit = live ? unit_raw : n - 1;  // clamp: dead lanes recompute the last unit, store nothing
     const UnitAddr ua(unit, blk);
@@ -256,9 +265,9 @@ __global__ __launch_bounds__(kBlock) void k_step_sens(const DevParams P, const f
     load_rows<13>(X, ua, xv);
     load_rows<7>(U, ua, uv);
     const float hv = dt_per_unit ? dt_per_unit[unit] : dt;
-    Dual<4> x[13];
+    Dual<kAnN> x[13];
     AnalyticCoeffs<MODEL> coeffs;
-    sens_update(P, coeffs, g, col, ua, xv, uv, hv, x, A, Bm, c, live);
+    sens_update<kAnN>(P, coeffs, g, col, ua, xv, uv, hv, x, A, Bm, c, live);
     if (!live) return;
     const UnitAddr uo = ua.late();
     if (g == 0) {
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void k_step_sens(const DevParams P, const f
 #pragma unroll
         for (int i = 0; i < 13; ++i) p[(long)i * blk] = x[i].v;
     }
-    SensIO::store(g, uo, x, A, Bm, c, true);
+    SensIOT<kAnN>::store(g, uo, x, A, Bm, c, true);
 }
 
 }  // namespace ac

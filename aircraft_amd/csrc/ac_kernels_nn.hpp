@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_step_sens(const DevParams P, c
     const float hv = dt_per_unit ? dt_per_unit[w.unit] : dt;
     Dual<4> x[13];
     MlpCoeffs<MlpEngine<6, WT, USE_MFMA>> coeffs(eng);
-    sens_update(P, coeffs, w.g, w.col, w.ua, xv, uv, hv, x, A, Bm, c, w.live);
+    sens_update<4>(P, coeffs, w.g, w.col, w.ua, xv, uv, hv, x, A, Bm, c, w.live);
     eng.drain();
     AC_MARK(eng.st, 7);  // [7] dual aero + rigid body + RK4 combine (everything outside forward())
     if (w.live) {

@@ -454,7 +454,7 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
     if (rc != AC_OK) return rc;
     if (n == 0) return AC_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = (int)((n + 63) / 64);  // 16 units per wave, 4 waves per workgroup
+    const int grid = (int)((n + 63) / 64);  // MLP: 16 units per wave, 4 waves per workgroup
     if (h->dp.p.model_kind == AC_MODEL_NN) {
         bool launched = false;
         AC_NN_CASE(2, true, (k_nn_step_sens<2, true>), grid, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c)
@@ -468,8 +468,12 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
         AC_HIP(hipGetLastError());
         return AC_OK;
     }
-    AC_LAUNCH_ANALYTIC(k_step_sens, grid, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c);
-    note_launch(h, "k_step_sens", grid, kBlock, 0);
+    // analytic: 4 N units per wave, N = directions per lane of the model (AnalyticSensN), 4 waves per workgroup
+    const int upb = 16 * (h->dp.p.model_kind == AC_MODEL_POLY ? AnalyticSensN<AC_MODEL_POLY>::value : AnalyticSensN<AC_MODEL_DEFAULT>::value);
+    static_assert(AnalyticSensN<AC_MODEL_DEFAULT>::value == AnalyticSensN<AC_MODEL_LINEAR>::value, "grid size below");
+    const int grid_an = (int)((n + upb - 1) / upb);
+    AC_LAUNCH_ANALYTIC(k_step_sens, grid_an, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c);
+    note_launch(h, "k_step_sens", grid_an, kBlock, 0);
     AC_HIP(hipGetLastError());
     return AC_OK;
 }
