@@ -11,10 +11,12 @@ from .dynamics.aircraft import Aircraft, AircraftOpts
 from .dynamics.coefficient_models import (COEFF_MODEL_REGISTRY, CoefficientModel, DefaultModel, LinearModel,
                                           NeuralModel, PolynomialModel)
 from ._lib import AircraftHipError
+from .trajectory_io import TrajectoryData, load_trajectory, save_trajectory
 
 __all__ = [
     "AircraftConfiguration", "TrajectoryConfiguration", "MlpData", "load_model", "load_poly", "load_linear",
     "SixDOF", "SixDOFOpts", "BatchedFunction", "Aircraft", "AircraftOpts", "COEFF_MODEL_REGISTRY",
     "CoefficientModel", "DefaultModel", "LinearModel", "NeuralModel", "PolynomialModel", "AircraftHipError",
+    "TrajectoryData", "load_trajectory", "save_trajectory",
 ]
 __version__ = "0.1.0"

@@ -18,7 +18,7 @@ STATUS_NAMES = {0: "AC_OK", -1: "AC_ERR_BAD_ARG", -2: "AC_ERR_HIP", -3: "AC_ERR_
 MODEL_KINDS = {"default": 0, "linear": 1, "nn": 2, "poly": 3}
 NUM_STATES = 13
 NUM_CONTROLS = 7
-AERO_ROWS = 20
+AERO_ROWS = 22
 MAX_LAYERS = 8
 MAX_WIDTH = 128
 

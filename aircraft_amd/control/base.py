@@ -68,6 +68,17 @@ class MultipleShooting:
         guess[: self.state_dim, :] = traj[:, :, 0].T
         return guess
 
+    # ---- trajectory files (the reference's SaveMixin, control/base.py:30-114) ----------------------
+    def save_progress(self, filepath, iteration, X, U, instance: int = 0, times=None, mode: str = "a"):
+        """Write one instance of a batch as `iteration_<k>/{state (13,N+1), control (7,N), times}` in the
+        reference's HDF5 layout, so its plotter (plotting/plotting.py:72-95) can read what was solved here."""
+        from ..trajectory_io import save_trajectory
+
+        Xi, Ui = X[:, :, instance].T, U[:, :, instance].T  # node-major buffers -> (13, N+1), (7, N)
+        if times is None:
+            times = self.dt * np.arange(Xi.shape[1])
+        save_trajectory(filepath, iteration, Xi, Ui, times, mode=mode)
+
     # ---- defects and their Jacobian blocks (HOT LOOPS #2/#3) ---------------------------------------
     def _shoot_args(self, X, U, dt):
         torch = _torch()

@@ -147,13 +147,19 @@ class ILQR(MultipleShooting):
         U.copy_(torch.where(improved[None, None, :], Un, U))
         return torch.where(improved, best, ws["J0"]), improved
 
-    def solve(self, x0, U0, iters: int = 10):
-        """Rollout from x0 with U0, then `iters` iLQR iterations.  Returns (X, U, cost history (iters+1, B))."""
+    def solve(self, x0, U0, iters: int = 10, save_to: Optional[str] = None, save_instance: int = 0):
+        """Rollout from x0 with U0, then `iters` iLQR iterations.  Returns (X, U, cost history (iters+1, B)).
+        `save_to` writes instance `save_instance` after every iteration in the reference's trajectory format
+        (iteration_0 = the initial rollout), the role of the IPOPT callback in control/base.py:60-86."""
         torch = _torch()
         U = U0.clone()
         X = self.rollout(x0, U)
         hist = [self.trajectory_cost(X, U).clone()]
-        for _ in range(iters):
+        if save_to:
+            self.save_progress(save_to, 0, X, U, save_instance, mode="w")
+        for it in range(iters):
             J, _ = self.iterate(x0, X, U)
             hist.append(J.clone())
+            if save_to:
+                self.save_progress(save_to, it + 1, X, U, save_instance)
         return X, U, torch.stack(hist)

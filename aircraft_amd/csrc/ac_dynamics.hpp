@@ -197,6 +197,14 @@ AC_DI void aero_post(const DevParams& P, const AeroPre<T>& a, const T u[7], T C[
     o.M[2] = Ma2 + (P.p.com[0] * o.F[1] - P.p.com[1] * o.F[0]);
 }
 
+// Euler angles of the attitude quaternion (dynamics/base.py:179-195)
+AC_DI void euler_angles(const float x[13], float& phi, float& theta, float& psi) {
+    const float qx = x[6], qy = x[7], qz = x[8], qw = x[9];
+    phi = atan2f(2.f * (qw * qx + qy * qz), 1.f - 2.f * (qx * qx + qy * qy));
+    theta = asinf(2.f * (qw * qy - qz * qx));
+    psi = atan2f(2.f * (qw * qz + qx * qy), 1.f - 2.f * (qy * qy + qz * qz));
+}
+
 template <class T> AC_DI void rigid_body(const DevParams& P, const T x[13], const AeroPost<T>& o, T xd[13]) {
     const Q4<T> q{x[6], x[7], x[8], x[9]};
     const T* w = &x[10];

@@ -122,9 +122,11 @@ __global__ __launch_bounds__(kBlock) void k_aero(const DevParams P, const float*
     coeffs(P, a, x, u, C);
     AeroPost<float> o;
     aero_post(P, a, u, C, o);
-    const float v[20] = {a.vr[0], a.vr[1], a.vr[2], a.V, a.alpha, a.beta, a.qbar, o.C[0], o.C[1], o.C[2],
-                         o.C[3], o.C[4], o.C[5], o.F[0], o.F[1], o.F[2], o.M[0], o.M[1], o.M[2], 0.f};
-    store_rows<20>(out, ua, v);
+    float eu[3];
+        euler_angles(x, eu[0], eu[1], eu[2]);
+        const float v[22] = {a.vr[0], a.vr[1], a.vr[2], a.V, a.alpha, a.beta, a.qbar, o.C[0], o.C[1], o.C[2],
+                         o.C[3], o.C[4], o.C[5], o.F[0], o.F[1], o.F[2], o.M[0], o.M[1], o.M[2], eu[0], eu[1], eu[2]};
+    store_rows<22>(out, ua, v);
 }
 
 // ---- sensitivities (direction layout: ac_dynamics.hpp, struct SeedsT) -----------------------------

@@ -102,9 +102,11 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_fwd(const DevParams P, const M
         AeroPost<float> o;
         aero_post(P, a, u, C, o);
         eng.drain();
-        const float v[20] = {a.vr[0], a.vr[1], a.vr[2], a.V, a.alpha, a.beta, a.qbar, o.C[0], o.C[1], o.C[2],
-                             o.C[3], o.C[4], o.C[5], o.F[0], o.F[1], o.F[2], o.M[0], o.M[1], o.M[2], 0.f};
-        if (w.live && w.g == 0) store_rows<20>(out, w.ua, v);
+        float eu[3];
+        euler_angles(x, eu[0], eu[1], eu[2]);
+        const float v[22] = {a.vr[0], a.vr[1], a.vr[2], a.V, a.alpha, a.beta, a.qbar, o.C[0], o.C[1], o.C[2],
+                             o.C[3], o.C[4], o.C[5], o.F[0], o.F[1], o.F[2], o.M[0], o.M[1], o.M[2], eu[0], eu[1], eu[2]};
+        if (w.live && w.g == 0) store_rows<22>(out, w.ua, v);
     }
 }
 
@@ -148,9 +150,11 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_fwd4(const DevParams P, const 
         AeroPost<float> o;
         aero_post(P, a, u, C, o);
         eng.drain();
-        const float v[20] = {a.vr[0], a.vr[1], a.vr[2], a.V, a.alpha, a.beta, a.qbar, o.C[0], o.C[1], o.C[2],
-                             o.C[3], o.C[4], o.C[5], o.F[0], o.F[1], o.F[2], o.M[0], o.M[1], o.M[2], 0.f};
-        if (live) store_rows<20>(out, ua.late(), v);
+        float eu[3];
+        euler_angles(x, eu[0], eu[1], eu[2]);
+        const float v[22] = {a.vr[0], a.vr[1], a.vr[2], a.V, a.alpha, a.beta, a.qbar, o.C[0], o.C[1], o.C[2],
+                             o.C[3], o.C[4], o.C[5], o.F[0], o.F[1], o.F[2], o.M[0], o.M[1], o.M[2], eu[0], eu[1], eu[2]};
+        if (live) store_rows<22>(out, ua.late(), v);
     }
 }
 

@@ -296,21 +296,10 @@ class SixDOF(ABC):
     forces_frd = property(lambda self: self._getter("forces_frd", slice(13, 16)))
     moments_frd = property(lambda self: self._getter("moments_frd", slice(16, 19)))
 
-    def _euler(self, name, fn):
-        def f(x):
-            torch = _torch()
-            X, npx, vec = self._in(x, self.num_states, "x")
-            qx, qy, qz, qw = X[6], X[7], X[8], X[9]
-            return self._out(fn(torch, qx, qy, qz, qw), npx, vec)
-
-        return BatchedFunction(name, (self.num_states,), 1, f)
-
-    # Euler-angle getters are plain elementwise torch ops on the device (reference base.py:179-195)
-    phi = property(lambda self: self._euler(
-        "phi", lambda t, x, y, z, w: t.atan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y))))
-    theta = property(lambda self: self._euler("theta", lambda t, x, y, z, w: t.asin(2 * (w * y - z * x))))
-    psi = property(lambda self: self._euler(
-        "psi", lambda t, x, y, z, w: t.atan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z))))
+    # Euler angles of the attitude (reference base.py:179-195); state-only getters f(x)
+    phi = property(lambda self: self._getter("phi", 19))
+    theta = property(lambda self: self._getter("theta", 20))
+    psi = property(lambda self: self._getter("psi", 21))
 
     def last_launch(self):
         """(kernel name, grid, block, dynamic LDS bytes) of the most recent dispatch."""

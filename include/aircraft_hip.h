@@ -36,7 +36,7 @@ extern "C" {
 
 #define AC_NUM_STATES 13   /* SixDOF.num_states,   dynamics/base.py:101 */
 #define AC_NUM_CONTROLS 7  /* Aircraft.num_controls, dynamics/aircraft.py:162 */
-#define AC_AERO_ROWS 20
+#define AC_AERO_ROWS 22
 #define AC_MAX_LAYERS 8
 #define AC_MAX_WIDTH 128   /* widest MLP layer the register-resident MFMA engine supports */
 
@@ -123,8 +123,8 @@ int ac_shoot_step_f32(ac_handle* h, const float* X, const float* U, float dt, co
 int ac_shoot_sens_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long B,
                       long H, float* Xn, float* A, float* Bm, float* c, void* stream);
 
-/* Aerodynamic getters, out [20][n]: v_frd_rel(3), airspeed, alpha, beta, qbar, coefficients(6),
- * forces_frd(3), moments_frd(3), 0                  — dynamics/base.py:147-278, dynamics/aircraft.py:255-330 */
+/* Getters, out [22][n]: v_frd_rel(3), airspeed, alpha, beta, qbar, coefficients(6), forces_frd(3), moments_frd(3),
+ * phi, theta, psi (Euler angles of q)        — dynamics/base.py:147-278, dynamics/aircraft.py:255-330, base.py:179-195 */
 int ac_aero_f32(ac_handle* h, const float* X, const float* U, long n, float* out, void* stream);
 
 /* Trajectory cost + best-K selection used by the sharded random-restart driver (build-side).

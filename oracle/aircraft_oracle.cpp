@@ -501,10 +501,13 @@ int oracle_aero_f64(const oracle_params* p, const double* X, const double* U, lo
         gather(X, n, i, 13, x); gather(U, n, i, 7, u);
         Aero<double> a;
         aero<double>(*p, D, x, u, a);
-        double o[20] = {a.vr[0], a.vr[1], a.vr[2], a.V, a.alpha, a.beta, a.qbar, a.C[0], a.C[1], a.C[2],
-                        a.C[3], a.C[4], a.C[5], a.F[0], a.F[1], a.F[2], a.M[0], a.M[1], a.M[2], 0.0};
-        for (int r = 0; r < 19; ++r) out[(long)r * n + i] = o[r];
-        out[19L * n + i] = 0.0;
+        const double qx = x[6], qy = x[7], qz = x[8], qw = x[9];  // Euler getters, base.py:179-195
+        const double phi = std::atan2(2 * (qw * qx + qy * qz), 1 - 2 * (qx * qx + qy * qy));
+        const double theta = std::asin(2 * (qw * qy - qz * qx));
+        const double psi = std::atan2(2 * (qw * qz + qx * qy), 1 - 2 * (qy * qy + qz * qz));
+        double o[22] = {a.vr[0], a.vr[1], a.vr[2], a.V, a.alpha, a.beta, a.qbar, a.C[0], a.C[1], a.C[2],
+                        a.C[3], a.C[4], a.C[5], a.F[0], a.F[1], a.F[2], a.M[0], a.M[1], a.M[2], phi, theta, psi};
+        for (int r = 0; r < 22; ++r) out[(long)r * n + i] = o[r];
     }
     return 0;
 }

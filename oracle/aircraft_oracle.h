@@ -73,8 +73,8 @@ int oracle_rollout_f64(const oracle_params* p, const double* X0, const double* U
 int oracle_step_sens_f64(const oracle_params* p, const double* X, const double* U, const double* dt,
                          int dt_is_scalar, long n, double* Xn, double* A, double* Bm, double* c);
 
-/* Aerodynamic getters: out [20][n] = v_frd_rel(3), airspeed, alpha, beta, qbar,
- * coefficients(6), forces_frd(3), moments_frd(3)   — dynamics/base.py:147-278, aircraft.py:255-330 */
+/* Getters: out [22][n] = v_frd_rel(3), airspeed, alpha, beta, qbar, coefficients(6), forces_frd(3),
+ * moments_frd(3), phi, theta, psi   — dynamics/base.py:147-278, aircraft.py:255-330, base.py:179-195 */
 int oracle_aero_f64(const oracle_params* p, const double* X, const double* U, long n, double* out);
 
 /* Coefficient MLP alone: inputs [n][5] row-major -> outputs [n][6], jac [n][6][5] (may be NULL)

@@ -170,11 +170,12 @@ class Oracle:
         return Xn, A, Bm, c
 
     AERO_ROWS = {"v_frd_rel": slice(0, 3), "airspeed": 3, "alpha": 4, "beta": 5, "qbar": 6,
-                 "coefficients": slice(7, 13), "forces_frd": slice(13, 16), "moments_frd": slice(16, 19)}
+                 "coefficients": slice(7, 13), "forces_frd": slice(13, 16), "moments_frd": slice(16, 19),
+                 "phi": 19, "theta": 20, "psi": 21}
 
     def aero(self, X, U):
         X = _c64(X); U = _c64(U); n = X.shape[1]
-        out = np.empty((20, n))
+        out = np.empty((22, n))
         assert lib().oracle_aero_f64(C.byref(self.p), _dptr(X), _dptr(U), n, _dptr(out)) == 0
         return out
 

@@ -37,6 +37,16 @@ def decode_simulation_h5():
     assert np.allclose(control[1], 3.0)
     np.savez(f"{OUT}/simulation_h5.npz", state=state, control=control, times=times)
     print("simulation_h5.npz", state.shape, control.shape)
+    # the data file itself (11 KB) is the fixture for aircraft_amd.trajectory_io's reader; when an HDF5 C library is
+    # present, cross-check the raw-offset decode above against a real HDF5 read
+    import shutil
+    shutil.copyfile(f"{REF}/data/trajectories/simulation.h5", f"{OUT}/simulation.h5")
+    os.chmod(f"{OUT}/simulation.h5", 0o644)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from aircraft_amd import trajectory_io
+    if trajectory_io.hdf5_available():
+        t = trajectory_io.load_trajectory(f"{OUT}/simulation.h5", 0)
+        assert np.array_equal(t.state, state) and np.array_equal(t.control, control) and np.array_equal(t.times, times)
 
 
 class _Inert:

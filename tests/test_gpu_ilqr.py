@@ -91,6 +91,26 @@ def test_ilqr_cost_decreases(gpu, model, hidden, B):
     assert bool((Uo <= lim + 1e-6).all()) and bool((Uo >= torch.tensor(cost.u_min, device=Uo.device)[None, :, None] - 1e-6).all())
 
 
+def test_solve_writes_reference_trajectory_file(gpu, tmp_path):
+    """ILQR.solve(save_to=...) leaves one `iteration_k` group per iteration in the reference's HDF5 layout
+    (control/base.py:89-105); the last group is the returned trajectory of the chosen instance."""
+    from aircraft_amd import trajectory_io as tio
+
+    if not tio.hdf5_available():
+        pytest.skip("no HDF5 C library in this image")
+    ac, il, cost, X0, U = setup(gpu, "poly", None, B=32, H=20)
+    path = str(tmp_path / "solve.h5")
+    X, Uo, hist = il.solve(dev(X0, gpu), dev(np.zeros_like(U), gpu), iters=3, save_to=path, save_instance=5)
+    assert tio.list_iterations(path) == [0, 1, 2, 3]
+    last = tio.load_trajectory(path, 3)
+    assert last.state.shape == (13, 21) and last.control.shape == (7, 20) and last.times.shape == (21,)
+    assert np.array_equal(last.state, X[:, :, 5].T.cpu().numpy().astype(np.float64))
+    assert np.array_equal(last.control, Uo[:, :, 5].T.cpu().numpy().astype(np.float64))
+    assert np.allclose(last.times, il.dt * np.arange(21))
+    first = tio.load_trajectory(path, 0)
+    assert np.array_equal(first.state[:, 0], last.state[:, 0]) and not first.control.any()
+
+
 def test_receding_horizon_loop_eager_equals_graph(gpu):
     """The closed loop of main/mhe/mhtt.py:79-124 (solve, keep N-overlap nodes, restart from the last kept state):
     a hipGraph replay of one cycle reproduces the eager loop bit for bit, and the executed trajectory is continuous."""

@@ -177,3 +177,50 @@ def test_abi_status_codes_without_gpu():
     if not torch.cuda.is_available():
         assert lib.ac_create(C.byref(p), C.byref(h)) == -5  # AC_ERR_NO_DEVICE
         assert b"no HIP device" in lib.ac_last_error()
+
+
+# ---- trajectory files in the reference's HDF5 layout ---------------------------------------------
+def _need_hdf5():
+    from aircraft_amd import trajectory_io
+
+    if not trajectory_io.hdf5_available():
+        pytest.skip("no HDF5 C library in this image")
+    return trajectory_io
+
+
+def test_trajectory_io_reads_reference_file():
+    """tests/golden/simulation.h5 is the reference's own stored rollout (main/dynamics/dynamics.py:134-145)."""
+    tio = _need_hdf5()
+    path = os.path.join(os.path.dirname(__file__), "golden", "simulation.h5")
+    assert tio.list_iterations(path) == [0]
+    t = tio.load_trajectory(path, 0)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "simulation_h5.npz"))
+    assert np.array_equal(t.state, g["state"]) and np.array_equal(t.control, g["control"])
+    assert np.array_equal(t.times, g["times"]) and t.iteration == 0 and t.lam is None
+    missing = tio.load_trajectory(path, 7)  # plotting.py:86-94: unknown iteration -> all None
+    assert missing.state is None and missing.iteration is None
+
+
+def test_trajectory_io_round_trip(tmp_path):
+    tio = _need_hdf5()
+    rng = np.random.default_rng(0)
+    path = str(tmp_path / "traj.h5")
+    X, U, t = rng.normal(size=(13, 51)), rng.normal(size=(7, 50)), 0.01 * np.arange(51)
+    tio.save_trajectory(path, 0, X, U, t)
+    tio.save_trajectory(path, 3, X[:, :5], U[:, :4], t[:5], compress=False, extra={"lam": np.ones((20, 5))})
+    tio.save_trajectory(path, -2, X * 2, U * 2, None)  # negative iteration numbers occur (control/base.py:80)
+    assert tio.list_iterations(path) == [-2, 0, 3]
+    a = tio.load_trajectory(path, 0)
+    assert np.array_equal(a.state, X) and np.array_equal(a.control, U) and np.array_equal(a.times, t)
+    b = tio.load_trajectory(path, 3)
+    assert b.state.shape == (13, 5) and np.array_equal(b.lam, np.ones((20, 5)))
+    assert tio.load_trajectory(path, -2).times is None
+    # rewriting an iteration replaces its datasets (control/base.py:101-103)
+    tio.save_trajectory(path, 0, X[:, :7], U[:, :6], t[:7])
+    assert tio.load_trajectory(path, 0).state.shape == (13, 7)
+    # float32 torch tensors are accepted and stored as float64
+    import torch
+    tio.save_trajectory(path, 9, torch.ones(13, 4), torch.zeros(7, 3), torch.arange(4.0), mode="w")
+    assert tio.list_iterations(path) == [9] and tio.load_trajectory(path, 9).state.dtype == np.float64
+    with pytest.raises(FileNotFoundError):
+        tio.load_trajectory(str(tmp_path / "nope.h5"), 0)

@@ -83,6 +83,20 @@ def test_default_model_known_answers():
     assert np.allclose(a[13:16, 0], np.array(C[:3]) * qbar * GLIDER["reference_area"], rtol=1e-14)
 
 
+def test_euler_getters_known_answers():
+    """phi/theta/psi (base.py:179-195) invert the ZYX Euler -> quaternion map used by scipy's Rotation
+    (utils.py imports it for the initial attitude)."""
+    from scipy.spatial.transform import Rotation
+
+    rng = np.random.default_rng(4)
+    ang = np.stack([rng.uniform(-3, 3, 50), rng.uniform(-1.4, 1.4, 50), rng.uniform(-3, 3, 50)])  # psi, theta, phi
+    q = Rotation.from_euler("ZYX", ang.T).as_quat()  # xyzw
+    X = np.zeros((13, 50)); X[6:10] = q.T; X[3] = 30.0
+    a = glider_oracle("default").aero(X, np.zeros((7, 50)))
+    assert np.abs(a[19] - ang[2]).max() < 1e-12 and np.abs(a[20] - ang[1]).max() < 1e-12
+    assert np.abs(a[21] - ang[0]).max() < 1e-12
+
+
 def test_reference_test_invariants():
     """The intent of the reference's stale unit tests (src/aircraft/tests/test_dynamics.py:44-76)."""
     o = glider_oracle("default", normalise=True)
