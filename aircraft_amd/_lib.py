@@ -43,6 +43,13 @@ class IlqrCost(C.Structure):
                 ("x_goal", C.c_float * 13), ("u_min", C.c_float * 7), ("u_max", C.c_float * 7), ("reg", C.c_float)]
 
 
+class MhttWeights(C.Structure):
+    """struct ac_mhtt_weights (include/aircraft_hip.h); defaults are moving_horizon.py:47-55."""
+    _fields_ = [("w_tracking", C.c_float), ("w_progress", C.c_float), ("w_progress_rate", C.c_float),
+                ("w_backward", C.c_float), ("w_terminal_align", C.c_float), ("w_low_velocity", C.c_float),
+                ("w_control", C.c_float)]
+
+
 # every symbol include/aircraft_hip.h declares, with its prototype
 _FP = C.POINTER(C.c_float)
 _VP = C.c_void_p
@@ -64,6 +71,14 @@ PROTOTYPES = {
     "ac_traj_cost_f32": (C.c_int, [_VP, _VP, C.c_long, C.c_long, _FP, C.c_float, C.c_float, _VP, _VP]),
     "ac_ilqr_backward_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP]),
     "ac_ilqr_cost_f32": (C.c_int, [_VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
+    "ac_ilqr_backward_node_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP,
+                                            _VP]),
+    "ac_ilqr_cost_node_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_long, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
+    "ac_set_track": (C.c_int, [_VP, C.c_int, _FP, C.c_float]),
+    "ac_track_eval_f32": (C.c_int, [_VP, _VP, C.c_long, _VP, _VP, _VP]),
+    "ac_track_progress_f32": (C.c_int, [_VP, _VP, _VP, _VP, C.c_float, C.c_long, C.c_long, C.c_int, _VP, _VP, _VP, _VP,
+                                        _VP, _VP, _VP]),
+    "ac_mhtt_loss_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
     "ac_rollout_policy_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _FP, C.c_int, C.c_float, C.c_long, C.c_long,
                                         _VP, _VP, _VP]),
     "ac_last_error": (C.c_char_p, []),

@@ -1,5 +1,6 @@
 from .base import MultipleShooting
 from .ilqr import ILQR, QuadraticCost
-from .moving_horizon import RecedingHorizon
+from .moving_horizon import MHTT, MHTTWeights, RecedingHorizon
+from .track import Track
 
-__all__ = ["MultipleShooting", "ILQR", "QuadraticCost", "RecedingHorizon"]
+__all__ = ["MultipleShooting", "ILQR", "QuadraticCost", "RecedingHorizon", "MHTT", "MHTTWeights", "Track"]

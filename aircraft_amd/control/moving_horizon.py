@@ -13,7 +13,15 @@ captured once into a hipGraph (torch.cuda.CUDAGraph) and replayed — BASELINE c
 """
 from __future__ import annotations
 
-from .ilqr import ILQR
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .. import _lib
+from .ilqr import ILQR, QuadraticCost
+from .track import Track
 
 
 def _torch():
@@ -52,6 +60,8 @@ class RecedingHorizon:
         self.cost.copy_(J)
         # advance: the state reached after the kept nodes becomes the next initial state
         self.x0.copy_(self.X[self.keep])
+        if hasattr(s, "advance_progress"):  # MHTT: the progress reached at the last kept node (mhtt.py:105)
+            s.advance_progress(self.X, self.keep)
         if self.warm_start == "shift":
             tail = self.U[self.keep:].clone()
             self.U[: self.overlap].copy_(tail)
@@ -66,13 +76,19 @@ class RecedingHorizon:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             x0, U = self.x0.clone(), self.U.clone()
+            s0 = getattr(self.solver, "s0", None)  # MHTT carries the progress at node 0 across cycles
+            s0_saved = s0.clone() if s0 is not None else None
             self.cycle()  # warm-up launch outside capture (lazy initialisation, LDS attribute calls)
             torch.cuda.synchronize()
             self.x0.copy_(x0); self.U.copy_(U)
+            if s0 is not None:
+                s0.copy_(s0_saved)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
                 self.cycle()
             self.x0.copy_(x0); self.U.copy_(U)
+            if s0 is not None:
+                s0.copy_(s0_saved)
         torch.cuda.current_stream().wait_stream(side)
         self._graph = g
         return self
@@ -95,3 +111,177 @@ class RecedingHorizon:
                 hist.append(self.X[1 : self.keep + 1].clone())
                 del x_before
         return torch.cat(hist) if record else None
+
+
+@dataclass
+class MHTTWeights:
+    """Loss weights of the reference's MHTT.loss (control/moving_horizon.py:47-55)."""
+    w_tracking: float = 10.0
+    w_progress: float = 5.0
+    w_progress_rate: float = 2.0
+    w_backward: float = 50.0
+    w_terminal_align: float = 20.0
+    w_low_velocity: float = 10.0
+    w_control: float = 100.0
+
+    def struct(self) -> "_lib.MhttWeights":
+        return _lib.MhttWeights(self.w_tracking, self.w_progress, self.w_progress_rate, self.w_backward,
+                                self.w_terminal_align, self.w_low_velocity, self.w_control)
+
+
+class MHTT(ILQR):
+    """Moving-horizon track tracking for B instances — the track/progress part of the reference's `MHTT`
+    (control/moving_horizon.py:33-247) on the batched solver:
+
+        progress variable s_k per node, 0 <= s <= 1                                    :131-137
+        s_{k+1} <= s_k + (v_k . t^)/L dt + 0.05 (p_k - track(s_k)) . t^ / L            :147-168
+        loss = 10 tracking - 5 sum s - 2 sum s_dot + 50 backward + 10 slow + 20 |p_N - track(1)| + 100 |u|^2   :44-105
+        initialise(x0, s0): rollout + velocity-projection progress guess               :203-239
+
+    The NLP (IPOPT) is replaced by iLQR: progress follows its constraint at the bound (the loss rewards progress, so
+    the bound is active), each iteration linearises the dynamics (ac_shoot_sens_f32), freezes the progress sequence
+    to build a per-node diagonal-quadratic model of the loss (ac_track_progress_f32 -> ac_ilqr_backward_node_f32),
+    and accepts line-search candidates on the TRUE loss with their own progress recursion (ac_mhtt_loss_f32).
+    """
+
+    def __init__(self, *, system, track: Track, dt: float, num_nodes: int, opts: Optional[dict] = None,
+                 weights: Optional[MHTTWeights] = None, reg: float = 1.0,
+                 alphas: Sequence[float] = (1.0, 0.5, 0.25, 0.1, 0.03), **kwargs):
+        opts = opts if opts else {"time": "fixed", "quaternion": "integration", "integration": "explicit"}
+        assert opts.get("time", "fixed") == "fixed", "can only run mhtt with fixed time"  # moving_horizon.py:35
+        self.weights = weights or MHTTWeights()
+        cost = QuadraticCost(r=[2.0 * self.weights.w_control] * 7, reg=reg)  # w_control * |u|^2 = 1/2 u' (2 w) u
+        super().__init__(system=system, dt=dt, num_nodes=num_nodes, cost=cost, opts=opts, alphas=alphas)
+        self.track = track
+        self.track_length = track.length()
+        assert self.track_length > 1e-6  # moving_horizon.py:155
+        track.install(system)
+        self.s0 = None
+        self._mws = None
+
+    # ---- workspace --------------------------------------------------------------------------------------
+    def _mhtt_workspace(self, B, dev):
+        torch = _torch()
+        H, na = self.num_nodes, len(self.alphas)
+        key = (B, H, na, str(dev))
+        if self._mws is None or self._mws["key"] != key:
+            f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)  # noqa: E731
+            self._mws = dict(key=key, S=f(H + 1, B), Sc=f(H + 1, na * B), s0c=f(na * B), nq=f(H + 1, 13, B),
+                             nx=f(H + 1, 13, B), ng=f(H + 1, 13, B))
+        return self._mws
+
+    def set_progress(self, s0):
+        """Progress of every instance at node 0 (the `progress_guess_parameter[0]` pin, moving_horizon.py:139)."""
+        torch = _torch()
+        dev = self.system._device_obj()
+        s0 = torch.as_tensor(np.asarray(s0, dtype=np.float32) if not isinstance(s0, torch.Tensor) else s0)
+        s0 = s0.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        if self.s0 is not None and self.s0.shape == s0.shape:
+            self.s0.copy_(s0)  # keep the buffer: a captured graph reads it
+        else:
+            self.s0 = s0.clone()
+        return self.s0
+
+    # ---- progress recursion, loss ------------------------------------------------------------------------
+    def progress(self, X, s0=None, mode: int = 1, want_terms: bool = False, model=None, out=None):
+        """S (N+1, B) along X (N+1, 13, B) from s0 (B,).  mode 0 = initial guess, 1 = constraint at its bound.
+        want_terms adds (s_dot (N, B), tracking_error (N, B)); model = (node_q, node_xref, node_glin) to fill."""
+        torch = _torch()
+        lib = self.system._sync()
+        s0 = self.s0 if s0 is None else s0
+        H, B = X.shape[0] - 1, X.shape[2]
+        assert s0 is not None and s0.numel() == B, "set_progress() first: one s0 per instance"
+        S = out if out is not None else torch.empty((H + 1, B), device=X.device, dtype=torch.float32)
+        sd = torch.empty((H, B), device=X.device, dtype=torch.float32) if want_terms else None
+        te = torch.empty((H, B), device=X.device, dtype=torch.float32) if want_terms else None
+        w = self.weights.struct()
+        ptr = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)  # noqa: E731
+        nq, nx, ng = model if model is not None else (None, None, None)
+        _lib.check(lib.ac_track_progress_f32(self.system._handle, C.byref(w), X.data_ptr(), s0.data_ptr(),
+                                             C.c_float(self.dt), B, H, int(mode), S.data_ptr(), ptr(sd), ptr(te),
+                                             ptr(nq), ptr(nx), ptr(ng), self.system._stream()),
+                   "ac_track_progress_f32")
+        return (S, sd, te) if want_terms else S
+
+    def loss(self, X, U, S, out=None):
+        """MHTT.loss (moving_horizon.py:44-105) of every instance -> (B,)."""
+        torch = _torch()
+        lib = self.system._sync()
+        H, B = U.shape[0], U.shape[2]
+        if out is None:
+            out = torch.empty((B,), device=X.device, dtype=torch.float32)
+        w = self.weights.struct()
+        _lib.check(lib.ac_mhtt_loss_f32(self.system._handle, C.byref(w), X.data_ptr(), U.data_ptr(), S.data_ptr(), B, H,
+                                        out.data_ptr(), self.system._stream()), "ac_mhtt_loss_f32")
+        return out
+
+    def track_eval(self, s):
+        """Device evaluation of the track: s (n,) -> pos (3, n), tangent (3, n)."""
+        torch = _torch()
+        lib = self.system._sync()
+        s = s.contiguous()
+        n = s.numel()
+        pos = torch.empty((3, n), device=s.device, dtype=torch.float32)
+        tan = torch.empty((3, n), device=s.device, dtype=torch.float32)
+        _lib.check(lib.ac_track_eval_f32(self.system._handle, s.data_ptr(), n, pos.data_ptr(), tan.data_ptr(),
+                                         self.system._stream()), "ac_track_eval_f32")
+        return pos, tan
+
+    # ---- the reference's initial guess ----------------------------------------------------------------------
+    def initialise(self, initial_state, current_progress, controls=None):
+        """One instance, reference-shaped: array (13 + 7 + 1, N+1) = rollout of zero controls from `initial_state`
+        with the velocity-projection progress guess in the last row (moving_horizon.py:203-239)."""
+        torch = _torch()
+        N = self.num_nodes
+        guess = np.zeros((self.state_dim + self.control_dim + 1, N + 1))
+        if controls is not None:
+            guess[self.state_dim:-1, :] = np.asarray(controls, dtype=np.float64).reshape(self.control_dim, N + 1)
+        x0 = np.asarray(initial_state, dtype=np.float64).reshape(self.state_dim)
+        dev = self.system._device_obj()
+        U = torch.as_tensor(np.ascontiguousarray(guess[self.state_dim:-1, :N].T[:, :, None]), dtype=torch.float32, device=dev)
+        X = self.rollout(torch.as_tensor(x0[:, None], dtype=torch.float32, device=dev), U)
+        s0 = torch.full((1,), float(current_progress), dtype=torch.float32, device=dev)
+        S = self.progress(X, s0, mode=0)
+        guess[: self.state_dim, :] = X[:, :, 0].T.cpu().numpy()
+        guess[-1, :] = S[:, 0].cpu().numpy()
+        return guess
+
+    # ---- ILQR hooks: true loss for acceptance, frozen-progress model for the backward pass ------------------------
+    def trajectory_cost(self, X, U, out=None):
+        B = self.s0.numel()
+        ws = self._mhtt_workspace(B, U.device)
+        if X.shape[2] == B:
+            S = self.progress(X, self.s0, mode=1, out=ws["S"])
+        else:  # line-search candidates: column a*B + b starts from s0[b]
+            na = X.shape[2] // B
+            ws["s0c"].view(na, B).copy_(self.s0[None, :].expand(na, B))
+            S = self.progress(X, ws["s0c"], mode=1, out=ws["Sc"])
+        return self.loss(X, U, S, out=out)
+
+    def backward(self, X, U, A, Bm, out=None):
+        torch = _torch()
+        lib = self.system._sync()
+        H, B = U.shape[0], U.shape[2]
+        ws = self._mhtt_workspace(B, U.device)
+        self.progress(X, self.s0, mode=1, model=(ws["nq"], ws["nx"], ws["ng"]), out=ws["S"])
+        if out is None:
+            out = (torch.empty((H, 7, 13, B), device=X.device), torch.empty((H, 7, B), device=X.device),
+                   torch.empty((2, B), device=X.device))
+        K, kff, dV = out
+        _lib.check(lib.ac_ilqr_backward_node_f32(self.system._handle, self._cstruct(), ws["nq"].data_ptr(),
+                                                 ws["nx"].data_ptr(), ws["ng"].data_ptr(), X.data_ptr(), U.data_ptr(),
+                                                 A.data_ptr(), Bm.data_ptr(), B, H, K.data_ptr(), kff.data_ptr(),
+                                                 dV.data_ptr(), self.system._stream()), "ac_ilqr_backward_node_f32")
+        return K, kff, dV
+
+    def advance_progress(self, X, keep: int):
+        """Receding-horizon shift: s0 <- progress reached at node `keep` of the accepted trajectory (mhtt.py:87, 105)."""
+        ws = self._mhtt_workspace(self.s0.numel(), X.device)
+        S = self.progress(X, self.s0, mode=1, out=ws["S"])
+        self.s0.copy_(S[keep])
+
+    def solve(self, x0, s0, U0, iters: int = 10, **kw):
+        """(X, U, S, loss history (iters+1, B)) from initial states x0 (13, B), progress s0 (B,), controls U0 (N, 7, B)."""
+        self.set_progress(s0)
+        X, U, hist = super().solve(x0, U0, iters=iters, **kw)
+        return X, U, self.progress(X, self.s0, mode=1).clone(), hist

@@ -23,6 +23,28 @@ struct IlqrCost {
     float reg;  // Levenberg term added to the diagonal of Quu
 };
 
+// Optional per-node, per-instance state cost  l_k(x) = 1/2 sum_j q_k[j] (x_j - xref_k[j])^2 + glin_k . x  (k = 0..H,
+// node H is the terminal one).  When q != nullptr these arrays [H+1][13][Bn] replace q / qf / x_ref / x_goal of
+// IlqrCost; a candidate batch wider than Bn (line search) reads instance b % Bn.
+struct NodeCost {
+    const float* __restrict__ q;
+    const float* __restrict__ xref;
+    const float* __restrict__ glin;
+    long Bn;
+    AC_DI bool on() const { return q != nullptr; }
+    // value and gradient pieces of row j at node k
+    AC_DI void row(const IlqrCost& C, long k, bool terminal, int j, long b, float& qj, float& xr, float& gl) const {
+        if (on()) {
+            const long o = (k * 13 + j) * Bn + (b % Bn);
+            qj = q[o]; xr = xref[o]; gl = glin[o];
+        } else {
+            qj = terminal ? C.qf[j] : C.q[j];
+            xr = terminal ? C.x_goal[j] : C.x_ref[j];
+            gl = 0.f;
+        }
+    }
+};
+
 struct AlphaSet {
     int n;
     float a[8];
@@ -35,7 +57,7 @@ struct AlphaSet {
 constexpr int kIlqrFloats = 1024;  // LDS floats per instance (layout below)
 
 template <int kUnused = 0>  // template: this header is included by several translation units
-__global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const float* __restrict__ X,
+__global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const NodeCost N, const float* __restrict__ X,
                                                       const float* __restrict__ U, const float* __restrict__ A,
                                                       const float* __restrict__ Bm, long B, long H,
                                                       float* __restrict__ K, float* __restrict__ kff,
@@ -64,18 +86,23 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const fl
     // terminal condition
     if (j < 13) {
         const float xn = X[(H * 13 + j) * B + b];
-        svx[j] = C.qf[j] * (xn - C.x_goal[j]);
-        for (int i = 0; i < 13; ++i) sV[i * 13 + j] = (i == j) ? C.qf[j] : 0.f;
+        float qj, xr, gl;
+        N.row(C, H, true, j, b, qj, xr, gl);
+        svx[j] = fmaf(qj, xn - xr, gl);
+        for (int i = 0; i < 13; ++i) sV[i * 13 + j] = (i == j) ? qj : 0.f;
     }
     float dv1 = 0.f, dv2 = 0.f;
     __syncthreads();
 
     for (long k = H - 1; k >= 0; --k) {
         // load A_k, B_k (column j), stage gradients
+        float qjj = 0.f;  // this lane's diagonal entry of the stage Hessian
         if (j < 13) {
             for (int i = 0; i < 13; ++i) sA[i * 13 + j] = A[((k * 13 + i) * 13 + j) * B + b];
             const float xk = X[(k * 13 + j) * B + b];
-            sqx[j] = C.q[j] * (xk - C.x_ref[j]);
+            float xr, gl;
+            N.row(C, k, false, j, b, qjj, xr, gl);
+            sqx[j] = fmaf(qjj, xk - xr, gl);
         }
         if (j < 7) {
             for (int i = 0; i < 13; ++i) sB[i * 7 + j] = Bm[((k * 13 + i) * 7 + j) * B + b];
@@ -105,7 +132,7 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const fl
             qx = sqx[j];
             for (int m = 0; m < 13; ++m) qx = fmaf(sA[m * 13 + j], svx[m], qx);
             for (int i = 0; i < 13; ++i) {
-                float s = (i == j) ? C.q[j] : 0.f;
+                float s = (i == j) ? qjj : 0.f;
                 for (int m = 0; m < 13; ++m) s = fmaf(sA[m * 13 + i], sVA[m * 13 + j], s);
                 qxx[i] = s;
             }
@@ -209,20 +236,26 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const fl
 
 // ---- quadratic trajectory cost ---------------------------------------------------------------------
 template <int kUnused = 0>
-__global__ __launch_bounds__(kBlock) void k_ilqr_cost(const IlqrCost C, const float* __restrict__ X,
+__global__ __launch_bounds__(kBlock) void k_ilqr_cost(const IlqrCost C, const NodeCost N, const float* __restrict__ X,
                                                       const float* __restrict__ U, long B, long H,
                                                       float* __restrict__ cost) {
     const long b = (long)blockIdx.x * kBlock + threadIdx.x;
     if (b >= B) return;
     float acc = 0.f;
-    for (long k = 0; k < H; ++k) {
+    for (long k = 0; k <= H; ++k) {
 #pragma unroll
-        for (int i = 0; i < 13; ++i) { const float d = X[(k * 13 + i) * B + b] - C.x_ref[i]; acc = fmaf(0.5f * C.q[i] * d, d, acc); }
+        for (int i = 0; i < 13; ++i) {
+            float qi, xr, gl;
+            N.row(C, k, k == H, i, b, qi, xr, gl);
+            const float x = X[(k * 13 + i) * B + b], d = x - xr;
+            acc = fmaf(0.5f * qi * d, d, acc);
+            acc = fmaf(gl, x, acc);
+        }
+        if (k < H) {
 #pragma unroll
-        for (int i = 0; i < 7; ++i) { const float u = U[(k * 7 + i) * B + b]; acc = fmaf(0.5f * C.r[i] * u, u, acc); }
+            for (int i = 0; i < 7; ++i) { const float u = U[(k * 7 + i) * B + b]; acc = fmaf(0.5f * C.r[i] * u, u, acc); }
+        }
     }
-#pragma unroll
-    for (int i = 0; i < 13; ++i) { const float d = X[(H * 13 + i) * B + b] - C.x_goal[i]; acc = fmaf(0.5f * C.qf[i] * d, d, acc); }
     cost[b] = acc;
 }
 

@@ -11,6 +11,7 @@
 #include "ac_kernels_analytic.hpp"
 #include "ac_nn_decl.hpp"
 #include "ac_ilqr.hpp"
+#include "ac_track.hpp"
 
 using namespace ac;
 
@@ -60,6 +61,8 @@ struct ac_handle {
     int use_mfma;
     float* d_blob;  // packed MLP weights + biases (device)
     size_t blob_floats;
+    float* d_track;  // [nseg][3][4] segment cubics (device)
+    TrackDev track;
     // last launch (profiling aid)
     char last_name[64];
     int last_grid, last_block, last_lds;
@@ -152,6 +155,7 @@ int ac_create(const ac_params* params, ac_handle** out) {
 int ac_destroy(ac_handle* h) {
     if (!h) return AC_ERR_BAD_ARG;
     if (h->d_blob) (void)hipFree(h->d_blob);
+    if (h->d_track) (void)hipFree(h->d_track);
     delete h;
     return AC_OK;
 }
@@ -510,24 +514,102 @@ static IlqrCost to_dev_cost(const ac_ilqr_cost* c) {
 
 int ac_ilqr_backward_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* X, const float* U, const float* A,
                          const float* Bm, long B, long H, float* K, float* kff, float* dV, void* stream) {
+    return ac_ilqr_backward_node_f32(h, cost, nullptr, nullptr, nullptr, X, U, A, Bm, B, H, K, kff, dV, stream);
+}
+
+int ac_ilqr_backward_node_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* node_q, const float* node_xref,
+                              const float* node_glin, const float* X, const float* U, const float* A, const float* Bm,
+                              long B, long H, float* K, float* kff, float* dV, void* stream) {
     if (h && B == 0) return AC_OK;
     if (!h || !cost || !X || !U || !A || !Bm || !K || !kff || !dV || B < 0 || H < 1) return AC_ERR_BAD_ARG;
+    if ((node_q || node_xref || node_glin) && !(node_q && node_xref && node_glin)) return AC_ERR_BAD_ARG;
+    const NodeCost nc{node_q, node_xref, node_glin, B};
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)((B + 3) / 4);
-    hipLaunchKernelGGL(k_ilqr_backward<0>, grid, 64, 0, st, to_dev_cost(cost), X, U, A, Bm, B, H, K, kff, dV);
+    hipLaunchKernelGGL(k_ilqr_backward<0>, grid, 64, 0, st, to_dev_cost(cost), nc, X, U, A, Bm, B, H, K, kff, dV);
     note_launch(h, "k_ilqr_backward", grid, 64, 4 * kIlqrFloats * 4);
     AC_HIP(hipGetLastError());
     return AC_OK;
 }
 
-int ac_ilqr_cost_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* X, const float* U, long B, long H, float* out,
-                     void* stream) {
+int ac_ilqr_cost_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* X, const float* U, long B, long H,
+                     float* out, void* stream) {
+    return ac_ilqr_cost_node_f32(h, cost, nullptr, nullptr, nullptr, B, X, U, B, H, out, stream);
+}
+
+int ac_ilqr_cost_node_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* node_q, const float* node_xref,
+                          const float* node_glin, long Bn, const float* X, const float* U, long B, long H, float* out,
+                          void* stream) {
     if (h && B == 0) return AC_OK;
-    if (!h || !cost || !X || !U || !out || B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    if (!h || !cost || !X || !U || !out || B < 0 || H < 1) return AC_ERR_BAD_ARG;
+    if ((node_q || node_xref || node_glin) && !(node_q && node_xref && node_glin && Bn > 0)) return AC_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)((B + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_ilqr_cost<0>, grid, kBlock, 0, st, to_dev_cost(cost), X, U, B, H, out);
+    const NodeCost nc{node_q, node_xref, node_glin, Bn > 0 ? Bn : 1};
+    hipLaunchKernelGGL(k_ilqr_cost<0>, grid, kBlock, 0, st, to_dev_cost(cost), nc, X, U, B, H, out);
     note_launch(h, "k_ilqr_cost", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+// ---- track + progress terms -------------------------------------------------------------------------
+int ac_set_track(ac_handle* h, int n_segments, const float* coef, float length) {
+    if (!h || !coef || n_segments < 1 || !(length > 0.f)) return AC_ERR_BAD_ARG;
+    if (h->d_track) { (void)hipFree(h->d_track); h->d_track = nullptr; }
+    const size_t bytes = (size_t)n_segments * 12 * sizeof(float);
+    AC_HIP(hipMalloc((void**)&h->d_track, bytes));
+    AC_HIP(hipMemcpy(h->d_track, coef, bytes, hipMemcpyHostToDevice));
+    h->track.coef = h->d_track;
+    h->track.nseg = n_segments;
+    h->track.inv_length = 1.f / length;
+    const float* last = coef + (size_t)(n_segments - 1) * 12;
+    for (int a = 0; a < 3; ++a) h->track.end_pos[a] = last[a * 4] + last[a * 4 + 1] + last[a * 4 + 2] + last[a * 4 + 3];
+    return AC_OK;
+}
+
+int ac_track_eval_f32(ac_handle* h, const float* s, long n, float* pos, float* tangent, void* stream) {
+    if (h && n == 0) return AC_OK;
+    if (!h || !s || !pos || !tangent || n < 0) return AC_ERR_BAD_ARG;
+    if (!h->d_track) return AC_ERR_NO_MODEL;
+    const int grid = (int)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_track_eval, grid, kBlock, 0, (hipStream_t)stream, h->track, s, n, pos, tangent);
+    note_launch(h, "k_track_eval", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+static MhttWeights to_dev_weights(const ac_mhtt_weights* w) {
+    MhttWeights d{};
+    static_assert(sizeof(MhttWeights) == sizeof(ac_mhtt_weights), "ac_mhtt_weights layout");
+    if (w) memcpy(&d, w, sizeof(d));
+    return d;
+}
+
+int ac_track_progress_f32(ac_handle* h, const ac_mhtt_weights* weights, const float* X, const float* s0, float dt,
+                          long B, long H, int mode, float* S, float* s_dot, float* track_err, float* node_q,
+                          float* node_xref, float* node_glin, void* stream) {
+    if (h && B == 0) return AC_OK;
+    if (!h || !X || !s0 || !S || B < 0 || H < 1 || (mode != 0 && mode != 1)) return AC_ERR_BAD_ARG;
+    const bool any = node_q || node_xref || node_glin;
+    if (any && !(node_q && node_xref && node_glin && weights)) return AC_ERR_BAD_ARG;
+    if (!h->d_track) return AC_ERR_NO_MODEL;
+    const int grid = (int)((B + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_track_progress, grid, kBlock, 0, (hipStream_t)stream, h->track, to_dev_weights(weights), X, s0,
+                       dt, B, H, mode, S, s_dot, track_err, node_q, node_xref, node_glin);
+    note_launch(h, "k_track_progress", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_mhtt_loss_f32(ac_handle* h, const ac_mhtt_weights* weights, const float* X, const float* U, const float* S,
+                     long B, long H, float* J, void* stream) {
+    if (h && B == 0) return AC_OK;
+    if (!h || !weights || !X || !U || !S || !J || B < 0 || H < 1) return AC_ERR_BAD_ARG;
+    if (!h->d_track) return AC_ERR_NO_MODEL;
+    const int grid = (int)((B + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_mhtt_loss, grid, kBlock, 0, (hipStream_t)stream, h->track, to_dev_weights(weights), X, U, S, B,
+                       H, J);
+    note_launch(h, "k_mhtt_loss", grid, kBlock, 0);
     AC_HIP(hipGetLastError());
     return AC_OK;
 }

@@ -158,6 +158,44 @@ int ac_rollout_policy_f32(ac_handle* h, const ac_ilqr_cost* limits, const float*
                           const float* U, const float* K, const float* kff, const float* alphas, int n_alpha, float dt,
                           long B, long H, float* Xout, float* Uout, void* stream);
 
+/* Per-node, per-instance state cost for the two calls above (device arrays [H+1][13][Bn], node H = terminal):
+ *   l_k(x) = 1/2 sum_j node_q[k][j] (x_j - node_xref[k][j])^2 + node_glin[k] . x
+ * replacing the q, qf, x_ref, x_goal fields of the cost struct; r, limits and reg still come from it.  A batch wider than Bn
+ * (the line-search candidates) reads instance b % Bn.  Produced by ac_track_progress_f32 for the MHTT loss. */
+int ac_ilqr_backward_node_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* node_q, const float* node_xref,
+                              const float* node_glin, const float* X, const float* U, const float* A, const float* Bm,
+                              long B, long H, float* K, float* kff, float* dV, void* stream);
+int ac_ilqr_cost_node_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* node_q, const float* node_xref,
+                          const float* node_glin, long Bn, const float* X, const float* U, long B, long H, float* out,
+                          void* stream);
+
+/* ---- track + progress terms of the moving-horizon track tracker   ---------------------------
+ * Track: piecewise cubic Hermite curve over s in [0,1] through the sampled Dubins path
+ * (control/initialisation.py:782-851).  `coef` is a HOST array [n_segments][3][4]: per segment and axis the cubic
+ * c0 + c1 t + c2 t^2 + c3 t^3 in the local parameter t = s*n_segments - segment (the host layer computes the
+ * Hermite slopes in float64, aircraft_amd/control/track.py); `length` is DubinsInitialiser.length()
+ * (initialisation.py:738-758).  The handle keeps a device copy. */
+int ac_set_track(ac_handle* h, int n_segments, const float* coef, float length);
+/* pos [3][n], tangent [3][n] = track.eval(s), track.eval_tangent(s) for s [n] (device) */
+int ac_track_eval_f32(ac_handle* h, const float* s, long n, float* pos, float* tangent, void* stream);
+
+typedef struct ac_mhtt_weights { /* control/moving_horizon.py:47-55 */
+    float w_tracking, w_progress, w_progress_rate, w_backward, w_terminal_align, w_low_velocity, w_control;
+} ac_mhtt_weights;
+
+/* Progress along the track for all nodes of all instances: X [H+1][13][B], s0 [B] -> S [H+1][B],
+ * s_dot [H][B] (may be NULL), track_err [H][B] = |p_k - track(s_k)|^2 (may be NULL).
+ *   mode 0: s_{k+1} = clip(s_k + s_dot dt, 0, 1)                    the initial guess, moving_horizon.py:216-233
+ *   mode 1: s_{k+1} = clip(s_k + s_dot dt + 0.05 delta_s, 0, 1)     the constraint row at its bound, :161-168
+ * If node_q/node_xref/node_glin [H+1][13][B] are non-NULL (all three), the diagonal-quadratic model of the MHTT
+ * loss around this progress sequence is written for ac_ilqr_*_node_f32 (weights may be NULL otherwise). */
+int ac_track_progress_f32(ac_handle* h, const ac_mhtt_weights* weights, const float* X, const float* s0, float dt,
+                          long B, long H, int mode, float* S, float* s_dot, float* track_err, float* node_q,
+                          float* node_xref, float* node_glin, void* stream);
+/* J [B] = MHTT.loss (moving_horizon.py:44-105) of X [H+1][13][B], U [H][7][B] with progress S [H+1][B] */
+int ac_mhtt_loss_f32(ac_handle* h, const ac_mhtt_weights* weights, const float* X, const float* U, const float* S,
+                     long B, long H, float* J, void* stream);
+
 /* Diagnostics */
 const char* ac_last_error(void);     /* thread-local text of the last failing HIP call */
 const char* ac_version(void);

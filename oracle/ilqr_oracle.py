@@ -6,8 +6,13 @@ instances: meant for small cases."""
 import numpy as np
 
 
-def cost(c, X, U):
-    """X (H+1,13,B), U (H,7,B) -> (B,)"""
+def cost(c, X, U, node=None):
+    """X (H+1,13,B), U (H,7,B) -> (B,).  node = (q, xref, glin), each (H+1,13,Bn): per-node state cost replacing
+    q/qf/x_ref/x_goal (include/aircraft_hip.h, ac_ilqr_cost_node_f32); instance b reads column b % Bn."""
+    if node is not None:
+        nq, nx, ng = (np.tile(a, (1, 1, X.shape[2] // a.shape[2])) for a in node)
+        d = X - nx
+        return (0.5 * nq * d * d + ng * X).sum(axis=(0, 1)) + 0.5 * (np.asarray(c.r)[None, :, None] * U * U).sum(axis=(0, 1))
     q, qf, r = np.asarray(c.q), np.asarray(c.qf), np.asarray(c.r)
     dx = X[:-1] - np.asarray(c.x_ref)[None, :, None]
     dg = X[-1] - np.asarray(c.x_goal)[:, None]
@@ -15,16 +20,22 @@ def cost(c, X, U):
         0.5 * (qf[:, None] * dg * dg).sum(axis=0)
 
 
-def backward(c, X, U, A, Bm):
+def backward(c, X, U, A, Bm, node=None):
     """A (H,13,13,B), Bm (H,13,7,B) -> K (H,7,13,B), kff (H,7,B), dV (2,B)"""
     H, _, B = U.shape
     q, qf, r = np.asarray(c.q, float), np.asarray(c.qf, float), np.asarray(c.r, float)
     K = np.zeros((H, 7, 13, B)); kff = np.zeros((H, 7, B)); dV = np.zeros((2, B))
     for b in range(B):
-        Vx = qf * (X[H, :, b] - np.asarray(c.x_goal)); Vxx = np.diag(qf)
+        if node is None:
+            Vx = qf * (X[H, :, b] - np.asarray(c.x_goal)); Vxx = np.diag(qf)
+        else:
+            Vx = node[0][H, :, b] * (X[H, :, b] - node[1][H, :, b]) + node[2][H, :, b]; Vxx = np.diag(node[0][H, :, b])
         for k in range(H - 1, -1, -1):
             Ak, Bk = A[k, :, :, b], Bm[k, :, :, b]
             lx = q * (X[k, :, b] - np.asarray(c.x_ref)); lu = r * U[k, :, b]
+            if node is not None:
+                q = node[0][k, :, b]
+                lx = q * (X[k, :, b] - node[1][k, :, b]) + node[2][k, :, b]
             Qx = lx + Ak.T @ Vx; Qu = lu + Bk.T @ Vx
             Qxx = np.diag(q) + Ak.T @ Vxx @ Ak
             Qux = Bk.T @ Vxx @ Ak
