@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""The reference's moving-horizon track-tracking driver (main/mhe/mhtt.py:40-124) for B gliders at once: poly
+coefficient model, trim start state, the MHTT loss with the reference's weights, a sliding window that keeps the first
+N - overlap nodes of every solve, until the batch reaches the end of the track.
+
+    python examples/mhtt_track.py --batch 1024 --save /tmp/mhtt.h5
+    python examples/mhtt_track.py --nodes 50 --dt 0.01 --substeps 1 --overlap 30 --iters 2   # the reference's window
+
+Each cycle is `--iters` batched iLQR iterations on the MHTT loss (track tangent projection, progress recursion); one
+cycle is captured into a hipGraph.  The default window is 3 s (100 nodes of 0.03 s, 3 RK4 substeps each): with the
+reference's own 0.5 s window (N = 50, dt = 0.01, main/mhe/mhtt.py:62) a position error cannot reach the control
+surfaces through four integrations within the horizon, and the loop — like any solver of that NLP — barely steers.
+The track is a climbing S-bend sampled like a Dubins path (the Dubins construction itself is not part of this
+package — pass its sampled points to `Track`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def s_bend(radius=600.0, sweep=0.4, z0=-200.0, climb=-10.0, n=81):
+    """Left arc then right arc, starting at the origin heading +x (NED: z negative is up)."""
+    th = np.linspace(0, sweep, n // 2 + 1)
+    a = np.stack([radius * np.sin(th), radius * (1 - np.cos(th))], axis=1)
+    c, s = np.cos(sweep), np.sin(sweep)
+    b_local = np.stack([radius * np.sin(th), -radius * (1 - np.cos(th))], axis=1)[1:]
+    b = a[-1] + b_local @ np.array([[c, s], [-s, c]])
+    xy = np.concatenate([a, b])
+    z = z0 + climb * np.linspace(0, 1, len(xy))
+    return np.concatenate([xy, z[:, None]], axis=1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--nodes", type=int, default=100)
+    ap.add_argument("--dt", type=float, default=0.03)
+    ap.add_argument("--substeps", type=int, default=3)
+    ap.add_argument("--overlap", type=int, default=60)
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--max-cycles", type=int, default=40)
+    ap.add_argument("--stop-progress", type=float, default=0.9, help="stop once the median progress passes this")
+    ap.add_argument("--poly-path", type=str, default=os.path.join(ROOT, "tests", "golden", "poly_coef.npz"))
+    ap.add_argument("--save", type=str, default="")
+    ap.add_argument("--eager", action="store_true", help="do not capture the cycle into a hipGraph")
+    args = ap.parse_args()
+
+    import torch
+
+    from aircraft_amd import Aircraft, AircraftConfiguration, AircraftOpts
+    from aircraft_amd.control import MHTT, RecedingHorizon, Track
+    from aircraft_amd.synthetic import GLIDER, TRIM_STATE
+    from aircraft_amd.trajectory_io import save_trajectory
+
+    dev = torch.device("cuda", 0)
+    ac = Aircraft(AircraftOpts(coeff_model_type="poly", coeff_model_path=args.poly_path,
+                               aircraft_config=AircraftConfiguration(dict(GLIDER)),
+                               physical_integration_substeps=args.substeps))
+    track = Track(s_bend())
+    mhtt = MHTT(system=ac, track=track, dt=args.dt, num_nodes=args.nodes,
+                opts={"time": "fixed", "quaternion": "integration", "integration": "explicit"})
+    B, N = args.batch, args.nodes
+    rng = np.random.default_rng(0)
+    X0 = np.tile(np.asarray(TRIM_STATE, dtype=np.float64)[:, None], (1, B))
+    X0[1] += rng.uniform(-3, 3, B); X0[2] += rng.uniform(-2, 2, B)   # released a few metres off the track start
+    X0[3] += rng.uniform(-3, 3, B)
+    x0 = torch.as_tensor(X0, dtype=torch.float32, device=dev)
+    U0 = torch.zeros((N, 7, B), device=dev)
+    mhtt.set_progress(np.zeros(B))
+    loop = RecedingHorizon(mhtt, overlap=args.overlap, iterations=args.iters).allocate(x0, U0)
+    if not args.eager:
+        loop.capture()
+    keep = N - args.overlap
+    states, dists, cycles = [x0.clone()[None]], [], 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while cycles < args.max_cycles:
+        loop.step()
+        states.append(loop.X[1 : keep + 1].clone())
+        ref, _ = mhtt.track_eval(mhtt.s0)  # where each glider should be vs where it is, at the hand-over node
+        dists.append((loop.x0[:3] - ref).norm(dim=0))
+        cycles += 1
+        if cycles % 2 == 0 and float(mhtt.s0.median()) >= args.stop_progress:  # mhtt.py:100, checked every other cycle
+            break
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    traj = torch.cat(states)  # (cycles*keep + 1, 13, B)
+    s_end = mhtt.s0.cpu().numpy()
+    d = torch.stack(dists).cpu().numpy()
+    speed = traj[-1, 3:6].norm(dim=0).cpu().numpy()
+    out = {"instances": B, "window": {"nodes": N, "dt": args.dt, "substeps": args.substeps, "overlap": args.overlap,
+                                      "iters": args.iters},
+           "cycles": cycles, "executed_steps": cycles * keep, "flight_time_s": cycles * keep * args.dt,
+           "ms_per_cycle": 1e3 * wall / cycles, "solves_per_s": B * cycles / wall, "track_length_m": track.length(),
+           "progress_end": {"min": float(s_end.min()), "median": float(np.median(s_end)), "max": float(s_end.max())},
+           "distance_to_track_m": {"median": float(np.median(d)), "p95": float(np.percentile(d, 95)), "max": float(d.max())},
+           "final_speed_mps": {"min": float(speed.min()), "median": float(np.median(speed))},
+           "finite": bool(torch.isfinite(traj).all())}
+    print(json.dumps(out))
+    if args.save:
+        best = int(np.argmax(s_end))
+        T = traj.shape[0]
+        save_trajectory(args.save, 0, traj[:, :, best].T, torch.zeros(7, T - 1), args.dt * np.arange(T), mode="w")
+        print(f"instance {best} written to {args.save}")
+
+
+if __name__ == "__main__":
+    main()
