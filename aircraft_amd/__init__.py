@@ -8,6 +8,7 @@ include/aircraft_hip.h.  PyTorch is used for device buffers, streams and torch.d
 from .utils import AircraftConfiguration, TrajectoryConfiguration, MlpData, load_model, load_poly, load_linear
 from .dynamics.base import SixDOF, SixDOFOpts, BatchedFunction
 from .dynamics.aircraft import Aircraft, AircraftOpts
+from .dynamics.quadrotor import Quadrotor
 from .dynamics.coefficient_models import (COEFF_MODEL_REGISTRY, CoefficientModel, DefaultModel, LinearModel,
                                           NeuralModel, PolynomialModel)
 from ._lib import AircraftHipError
@@ -15,7 +16,7 @@ from .trajectory_io import TrajectoryData, load_trajectory, save_trajectory
 
 __all__ = [
     "AircraftConfiguration", "TrajectoryConfiguration", "MlpData", "load_model", "load_poly", "load_linear",
-    "SixDOF", "SixDOFOpts", "BatchedFunction", "Aircraft", "AircraftOpts", "COEFF_MODEL_REGISTRY",
+    "SixDOF", "SixDOFOpts", "BatchedFunction", "Aircraft", "AircraftOpts", "Quadrotor", "COEFF_MODEL_REGISTRY",
     "CoefficientModel", "DefaultModel", "LinearModel", "NeuralModel", "PolynomialModel", "AircraftHipError",
     "TrajectoryData", "load_trajectory", "save_trajectory",
 ]

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("AIRCRAFT_HIP_LIB") or os.path.join(_HERE, "libaircraf
 AC_OK = 0
 STATUS_NAMES = {0: "AC_OK", -1: "AC_ERR_BAD_ARG", -2: "AC_ERR_HIP", -3: "AC_ERR_UNSUPPORTED",
                 -4: "AC_ERR_NO_MODEL", -5: "AC_ERR_NO_DEVICE"}
-MODEL_KINDS = {"default": 0, "linear": 1, "nn": 2, "poly": 3}
+MODEL_KINDS = {"default": 0, "linear": 1, "nn": 2, "poly": 3, "quad": 4}
 NUM_STATES = 13
 NUM_CONTROLS = 7
 AERO_ROWS = 22

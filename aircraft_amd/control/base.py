@@ -85,7 +85,7 @@ class MultipleShooting:
         H, B = U.shape[0], U.shape[2]
         assert X.is_cuda and U.is_cuda and X.dtype == torch.float32 and U.dtype == torch.float32
         assert X.is_contiguous() and U.is_contiguous()
-        assert X.shape[0] >= H and X.shape[1] == self.state_dim and X.shape[2] == B and U.shape[1] == self.control_dim
+        assert X.shape[0] >= H and X.shape[1] == self.state_dim and X.shape[2] == B and U.shape[1] == _lib.NUM_CONTROLS  # device control rows
         if dt is None:
             dt = self.dt
         if isinstance(dt, torch.Tensor) and dt.numel() > 1:
@@ -117,7 +117,7 @@ class MultipleShooting:
         torch = _torch()
         lib = self.system._sync()
         H, B, dts, dtp, keep = self._shoot_args(X, U, dt)
-        ns, nc = self.state_dim, self.control_dim
+        ns, nc = self.state_dim, _lib.NUM_CONTROLS
         if out is None:
             F = torch.empty((H, ns, B), device=X.device, dtype=torch.float32)
             A = torch.empty((H, ns, ns, B), device=X.device, dtype=torch.float32)

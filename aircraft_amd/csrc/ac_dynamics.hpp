@@ -113,6 +113,7 @@ template <class T> AC_DI T poly_cz_alpha_only(const DevParams& P, const T& al) {
 //                           RK4 carry is live across the (register-hungry) network evaluation
 //   operator()(P, a, x, u, C)   turns the aerodynamic inputs (with tangents) into the six coefficients
 template <int MODEL> struct AnalyticCoeffs {
+    static constexpr int kModel = MODEL;
     template <class T> AC_DI void prefetch(const DevParams&, const T*, const float*) {}
     template <class T>
     AC_DI void operator()(const DevParams& P, const AeroPre<T>& a, const T x[13], const T u[7], T C[6]) const {
@@ -197,6 +198,21 @@ AC_DI void aero_post(const DevParams& P, const AeroPre<T>& a, const T u[7], T C[
     o.M[2] = Ma2 + (P.p.com[0] * o.F[1] - P.p.com[1] * o.F[0]);
 }
 
+// Quadrotor plugin (dynamics/quadrotor.py:43-54): forces and moments straight from the four rotor thrusts u[0..3];
+// the moment about the reference point picks up com x F like every SixDOF (dynamics/base.py:268-278).
+template <class T> AC_DI void quad_forces(const DevParams& P, const T u[7], AeroPost<T>& o) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o.C[k] = T(0.f);
+    o.F[0] = T(0.f); o.F[1] = T(0.f);
+    o.F[2] = u[0] + u[1] + u[2] + u[3];
+    const T Ma0 = u[0] - u[1] - u[2] + u[3];
+    const T Ma1 = u[2] + u[3] - u[0] - u[1];
+    const T Ma2 = 0.5f * (u[0] - u[1] + u[2] - u[3]);
+    o.M[0] = Ma0 + (P.p.com[1] * o.F[2] - P.p.com[2] * o.F[1]);
+    o.M[1] = Ma1 + (P.p.com[2] * o.F[0] - P.p.com[0] * o.F[2]);
+    o.M[2] = Ma2 + (P.p.com[0] * o.F[1] - P.p.com[1] * o.F[0]);
+}
+
 // Euler angles of the attitude quaternion (dynamics/base.py:179-195)
 AC_DI void euler_angles(const float x[13], float& phi, float& theta, float& psi) {
     const float qx = x[6], qy = x[7], qz = x[8], qw = x[9];
@@ -232,12 +248,16 @@ template <class T> AC_DI void rigid_body(const DevParams& P, const T x[13], cons
 // x_dot = f(x, u).  coeffs.prefetch(P, x, u-values) must have been called for this x.
 template <class T, class Coeffs>
 AC_DI void state_derivative(const DevParams& P, Coeffs& coeffs, const T x[13], const T u[7], T xd[13]) {
-    AeroPre<T> a;
-    aero_pre(P, x, a);
-    T C[6];
-    coeffs(P, a, x, u, C);
     AeroPost<T> o;
-    aero_post(P, a, u, C, o);
+    if constexpr (Coeffs::kModel == AC_MODEL_QUAD) {
+        quad_forces(P, u, o);
+    } else {
+        AeroPre<T> a;
+        aero_pre(P, x, a);
+        T C[6];
+        coeffs(P, a, x, u, C);
+        aero_post(P, a, u, C, o);
+    }
     rigid_body(P, x, o, xd);
 }
 
@@ -330,11 +350,13 @@ template <int N> struct SeedsT {
         for (int j = 0; j < N; ++j) r.d[j] = (i >= 3 && (i - 3) == N * g + j) ? 1.f : 0.f;
         return r;
     }
-    static AC_DI void controls(int g, const float uv[7], Dual<N> u[7]) {
+    // control directions 10..13: aircraft = aileron, elevator, rudder, flaps (rows 0, 1, 2, 6; thrust rows have no
+    // effect); quadrotor = its four thrusts (rows 0..3)
+    template <bool QUAD> static AC_DI void controls(int g, const float uv[7], Dual<N> u[7]) {
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             u[i].v = uv[i];
-            const int dir = (i < 3) ? 10 + i : (i == 6 ? 13 : -1);
+            const int dir = QUAD ? (i < 4 ? 10 + i : -1) : ((i < 3) ? 10 + i : (i == 6 ? 13 : -1));
 #pragma unroll
             for (int j = 0; j < N; ++j) u[i].d[j] = (dir == N * g + j) ? 1.f : 0.f;
         }
@@ -364,7 +386,7 @@ AC_DI void rk4_step_seeded(const DevParams& P, Coeffs& coeffs, int g, const floa
         asm volatile("" : "+v"(gg));  // keep the seed patterns out of loop-invariant registers
         {
             T u[7];
-            Seeds::controls(gg, uv, u);
+            Seeds::template controls<Coeffs::kModel == AC_MODEL_QUAD>(gg, uv, u);
             state_derivative(P, coeffs, xs, u, k);
         }
         const float wsum = (s == 1 || s == 2) ? 2.0f : 1.0f;

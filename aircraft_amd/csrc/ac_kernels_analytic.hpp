@@ -116,12 +116,16 @@ __global__ __launch_bounds__(kBlock) void k_aero(const DevParams P, const float*
     load_rows<7>(U, ua, u);
     AeroPre<float> a;
     aero_pre(P, x, a);
-    float C[6];
-    AnalyticCoeffs<MODEL> coeffs;
-    coeffs.prefetch(P, x, u);
-    coeffs(P, a, x, u, C);
     AeroPost<float> o;
-    aero_post(P, a, u, C, o);
+    if constexpr (MODEL == AC_MODEL_QUAD) {
+        quad_forces(P, u, o);
+    } else {
+        float C[6];
+        AnalyticCoeffs<MODEL> coeffs;
+        coeffs.prefetch(P, x, u);
+        coeffs(P, a, x, u, C);
+        aero_post(P, a, u, C, o);
+    }
     float eu[3];
         euler_angles(x, eu[0], eu[1], eu[2]);
         const float v[22] = {a.vr[0], a.vr[1], a.vr[2], a.V, a.alpha, a.beta, a.qbar, o.C[0], o.C[1], o.C[2],
@@ -130,12 +134,14 @@ __global__ __launch_bounds__(kBlock) void k_aero(const DevParams P, const float*
 }
 
 // ---- sensitivities (direction layout: ac_dynamics.hpp, struct SeedsT) -----------------------------
-template <int N> struct SensIOT {
+// QUAD: the quadrotor's control directions 10..13 are B columns 0..3 and columns 4..6 are the constant zeros
+// (aircraft: columns 0, 1, 2, 6 and zeros in the thrust columns 3..5).
+template <int N, bool QUAD = false> struct SensIOT {
     // column of direction d in the output arrays: base pointer + row stride (null = no column)
     static AC_DI void column(int d, long n, float* Au, float* Bu, float* cu, float*& base, long& stride) {
         if (d < 10) { base = Au + (long)(3 + d) * n; stride = 13 * n; }
         else if (d < 13) { base = Bu + (long)(d - 10) * n; stride = 7 * n; }
-        else if (d == 13) { base = Bu + 6L * n; stride = 7 * n; }
+        else if (d == 13) { base = Bu + (QUAD ? 3L : 6L) * n; stride = 7 * n; }
         else if (d == 14) { base = cu; stride = n; }
         else { base = nullptr; stride = 0; }
     }
@@ -160,7 +166,7 @@ template <int N> struct SensIOT {
 #pragma unroll
             for (int i = 0; i < 13; ++i) {
                 Au[((long)i * 13 + g) * n] = (i == g) ? 1.f : 0.f;  // dF/dp_g
-                Bu[((long)i * 7 + 3 + g) * n] = 0.f;               // dF/dthrust_g
+                Bu[((long)i * 7 + (QUAD ? 4 : 3) + g) * n] = 0.f;  // dF/d(control without effect)
             }
         }
     }
@@ -196,6 +202,7 @@ AC_DI void sens_update(const DevParams& P, Coeffs& coeffs, int g, int col, const
                        const float uv[7], float dt, Dual<N> x[13], float* __restrict__ A, float* __restrict__ Bm,
                        float* __restrict__ c, bool live) {
     constexpr int UPW = 4 * N;  // units per wave
+    typedef SensIOT<N, Coeffs::kModel == AC_MODEL_QUAD> IO;
     const int ns = P.p.substeps < 1 ? 1 : P.p.substeps;
     const float hv = (ns == 1) ? dt : dt / (float)ns;
     const float dh = 1.0f / (float)ns;
@@ -206,7 +213,7 @@ AC_DI void sens_update(const DevParams& P, Coeffs& coeffs, int g, int col, const
             const UnitAddr ul = ua.late();  // addresses computed here, not hoisted to kernel entry
             if (s > 0) {
                 Dual<N> told[13], tnew[13];
-                if (live) SensIOT<N>::load(g, ul, told, A, Bm, c);
+                if (live) IO::load(g, ul, told, A, Bm, c);
                 else {
 #pragma unroll
                     for (int i = 0; i < 13; ++i) told[i] = Dual<N>(0.f);
@@ -236,7 +243,7 @@ AC_DI void sens_update(const DevParams& P, Coeffs& coeffs, int g, int col, const
                     for (int j = 0; j < N; ++j) x[i].d[j] = tnew[i].d[j];
                 }
             }
-            if (live) SensIOT<N>::store(g, ul, x, A, Bm, c, false);
+            if (live) IO::store(g, ul, x, A, Bm, c, false);
             __builtin_amdgcn_s_waitcnt(0);  // own stores retired before the next sub-step reads them back
 #pragma unroll
             for (int i = 0; i < 13; ++i) xv[i] = x[i].v;
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void k_step_sens(const DevParams P, const f
 #pragma unroll
         for (int i = 0; i < 13; ++i) p[(long)i * blk] = x[i].v;
     }
-    SensIOT<kAnN>::store(g, uo, x, A, Bm, c, true);
+    SensIOT<kAnN, MODEL == AC_MODEL_QUAD>::store(g, uo, x, A, Bm, c, true);
 }
 
 }  // namespace ac

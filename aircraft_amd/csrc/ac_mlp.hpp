@@ -597,6 +597,7 @@ struct MlpEngineCoopReg {
 // output scaler and, for duals, the chain rule  dC = J . d(inputs)  — the custom-Jacobian rule l4casadi
 // supplies to CasADi in the reference (coefficient_models.py:93-100).
 template <class Engine> struct MlpCoeffs {
+    static constexpr int kModel = AC_MODEL_NN;
     Engine& eng;
     float y[6];
     float J[Engine::kTangent ? 6 : 1][5];

@@ -78,7 +78,7 @@ void note_launch(ac_handle* h, const char* name, int grid, int block, int lds) {
 int check_params(const ac_params* p) {
     if (!p) return AC_ERR_BAD_ARG;
     if (p->substeps < 1) return AC_ERR_BAD_ARG;
-    if (p->model_kind < AC_MODEL_DEFAULT || p->model_kind > AC_MODEL_POLY) return AC_ERR_BAD_ARG;
+    if (p->model_kind < AC_MODEL_DEFAULT || p->model_kind > AC_MODEL_QUAD) return AC_ERR_BAD_ARG;
     return AC_OK;
 }
 
@@ -103,6 +103,7 @@ template <class K> int set_lds_limit(K kernel, int bytes) {
         switch (h->dp.p.model_kind) {                                                                       \
             case AC_MODEL_LINEAR: hipLaunchKernelGGL(KERNEL<AC_MODEL_LINEAR>, GRID, BLOCK, 0, st, h->dp, __VA_ARGS__); break; \
             case AC_MODEL_POLY: hipLaunchKernelGGL(KERNEL<AC_MODEL_POLY>, GRID, BLOCK, 0, st, h->dp, __VA_ARGS__); break;     \
+            case AC_MODEL_QUAD: hipLaunchKernelGGL(KERNEL<AC_MODEL_QUAD>, GRID, BLOCK, 0, st, h->dp, __VA_ARGS__); break;     \
             default: hipLaunchKernelGGL(KERNEL<AC_MODEL_DEFAULT>, GRID, BLOCK, 0, st, h->dp, __VA_ARGS__); break;             \
         }                                                                                                   \
     } while (0)
@@ -673,6 +674,7 @@ int ac_rollout_policy_f32(ac_handle* h, const ac_ilqr_cost* limits, const float*
     switch (h->dp.p.model_kind) {
         case AC_MODEL_LINEAR: hipLaunchKernelGGL(k_rollout_policy<AC_MODEL_LINEAR>, grid, 64, 0, st, h->dp, pol, X0, dt, Bout, H, Xout, Uout); break;
         case AC_MODEL_POLY: hipLaunchKernelGGL(k_rollout_policy<AC_MODEL_POLY>, grid, 64, 0, st, h->dp, pol, X0, dt, Bout, H, Xout, Uout); break;
+        case AC_MODEL_QUAD: hipLaunchKernelGGL(k_rollout_policy<AC_MODEL_QUAD>, grid, 64, 0, st, h->dp, pol, X0, dt, Bout, H, Xout, Uout); break;
         default: hipLaunchKernelGGL(k_rollout_policy<AC_MODEL_DEFAULT>, grid, 64, 0, st, h->dp, pol, X0, dt, Bout, H, Xout, Uout); break;
     }
     note_launch(h, "k_rollout_policy", grid, 64, 0);

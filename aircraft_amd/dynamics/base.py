@@ -131,6 +131,19 @@ class SixDOF(ABC):
             pass
 
     # ---- tensor hand-off --------------------------------------------------------------------
+    def _in_u(self, u):
+        """Controls -> the 7-row device layout.  A plugin with fewer controls (the quadrotor's four thrusts) passes
+        (num_controls, n); rows beyond are zero and ignored by its kernels.  A ready 7-row buffer passes through."""
+        torch = _torch()
+        rows = self.num_controls
+        shape = tuple(getattr(u, "shape", ()))
+        if rows < _lib.NUM_CONTROLS and len(shape) >= 1 and shape[0] == _lib.NUM_CONTROLS:
+            rows = _lib.NUM_CONTROLS
+        U, npu, vec = self._in(u, rows, "u")
+        if rows < _lib.NUM_CONTROLS:
+            U = torch.cat([U, torch.zeros((_lib.NUM_CONTROLS - rows, U.shape[1]), device=U.device, dtype=U.dtype)])
+        return U, npu, vec
+
     def _in(self, a, rows, name):
         """-> (float32 contiguous cuda tensor (rows, n), came_from_numpy, was_vector)"""
         torch = _torch()
@@ -174,7 +187,7 @@ class SixDOF(ABC):
             lib = self._sync()
             torch = _torch()
             X, npx, vec = self._in(x, self.num_states, "x")
-            U, _, _ = self._in(u, self.num_controls, "u")
+            U, _, _ = self._in_u(u)
             n = X.shape[1]
             if U.shape[1] != n:
                 raise ValueError("x and u must have the same number of columns")
@@ -193,7 +206,7 @@ class SixDOF(ABC):
             lib = self._sync()
             torch = _torch()
             X, npx, vec = self._in(x, self.num_states, "x")
-            U, _, _ = self._in(u, self.num_controls, "u")
+            U, _, _ = self._in_u(u)
             n = X.shape[1]
             if U.shape[1] != n:
                 raise ValueError("x and u must have the same number of columns")
@@ -217,9 +230,12 @@ class SixDOF(ABC):
         Ut = torch.as_tensor(np.asarray(U, dtype=np.float32) if from_np else U)
         if vec and Ut.dim() == 2:
             Ut = Ut.unsqueeze(-1)
-        if Ut.dim() != 3 or Ut.shape[1] != self.num_controls or Ut.shape[2] != B:
+        if Ut.dim() != 3 or Ut.shape[1] not in (self.num_controls, _lib.NUM_CONTROLS) or Ut.shape[2] != B:
             raise ValueError(f"U: expected (H, {self.num_controls}, {B}), got {tuple(Ut.shape)}")
-        Ut = Ut.to(device=X0.device, dtype=torch.float32).contiguous()
+        Ut = Ut.to(device=X0.device, dtype=torch.float32)
+        if Ut.shape[1] < _lib.NUM_CONTROLS:  # fewer controls than device rows: zero-fill (see _in_u)
+            Ut = torch.cat([Ut, torch.zeros((Ut.shape[0], _lib.NUM_CONTROLS - Ut.shape[1], B), device=Ut.device)], dim=1)
+        Ut = Ut.contiguous()
         H = Ut.shape[0]
         if out is None:
             out = torch.empty((H + 1, self.num_states, B), device=X0.device, dtype=torch.float32)
@@ -239,12 +255,13 @@ class SixDOF(ABC):
         lib = self._sync()
         torch = _torch()
         X, npx, vec = self._in(x, self.num_states, "x")
-        U, _, _ = self._in(u, self.num_controls, "u")
+        U, _, _ = self._in_u(u)
         n = X.shape[1]
         if U.shape[1] != n:
             raise ValueError("x and u must have the same number of columns")
         dts, dtp, keep = self._dt_args(dt, n)
-        ns, nc = self.num_states, self.num_controls
+        ns, nc = self.num_states, _lib.NUM_CONTROLS
+        fresh = out is None
         if out is None:
             Xn = torch.empty_like(X)
             A = torch.empty((ns, ns, n), device=X.device, dtype=torch.float32)
@@ -259,6 +276,8 @@ class SixDOF(ABC):
         if npx:
             cv = (lambda t: None if t is None else t.cpu().numpy().astype(np.float64))
             Xn, A, Bm, c = cv(Xn), cv(A), cv(Bm), cv(c)
+        if fresh and self.num_controls < nc:
+            Bm = Bm[:, : self.num_controls]  # the plugin's own controls; the remaining columns are zero
         if vec:
             Xn, A, Bm = Xn[..., 0], A[..., 0], Bm[..., 0]
             c = None if c is None else c[..., 0]
@@ -270,9 +289,9 @@ class SixDOF(ABC):
         torch = _torch()
         X, npx, vec = self._in(x, self.num_states, "x")
         if u is None:
-            U = torch.zeros((self.num_controls, X.shape[1]), device=X.device, dtype=torch.float32)
+            U = torch.zeros((_lib.NUM_CONTROLS, X.shape[1]), device=X.device, dtype=torch.float32)
         else:
-            U, _, _ = self._in(u, self.num_controls, "u")
+            U, _, _ = self._in_u(u)
         n = X.shape[1]
         out = torch.empty((_lib.AERO_ROWS, n), device=X.device, dtype=torch.float32)
         _lib.check(lib.ac_aero_f32(self._handle, X.data_ptr(), U.data_ptr(), n, out.data_ptr(), self._stream()),

@@ -50,7 +50,11 @@ typedef enum ac_status {
 } ac_status;
 
 /* Registry keys of COEFF_MODEL_REGISTRY, dynamics/coefficient_models.py:32-37 */
-typedef enum ac_model_kind { AC_MODEL_DEFAULT = 0, AC_MODEL_LINEAR = 1, AC_MODEL_NN = 2, AC_MODEL_POLY = 3 } ac_model_kind;
+typedef enum ac_model_kind { AC_MODEL_DEFAULT = 0, AC_MODEL_LINEAR = 1, AC_MODEL_NN = 2, AC_MODEL_POLY = 3,
+                             /* not a coefficient model: the Quadrotor plugin (dynamics/quadrotor.py:8-54) — body force
+                              * (0, 0, sum T) and rotor moments straight from control rows 0-3 (the four thrusts);
+                              * control rows 4-6 are ignored and their Jacobian columns are zero. */
+                             AC_MODEL_QUAD = 4 } ac_model_kind;
 
 /* Constants of one airframe + integration options.
  * Mirrors AircraftOpts / SixDOFOpts / AircraftConfiguration

@@ -140,7 +140,8 @@ void make_derived(const oracle_params& P, Derived& D) {
     const double I0[3][3] = {{P.Ixx, 0.0, P.Ixz}, {0.0, P.Iyy, 0.0}, {P.Ixz, 0.0, P.Izz}};
     const double K[3][3] = {{y * y + z * z, -x * y, -x * z}, {-y * x, x * x + z * z, -y * z}, {-z * x, -z * y, x * x + y * y}};
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) D.I[i][j] = I0[i][j] + m * K[i][j];
+        for (int j = 0; j < 3; ++j)  // the parallel-axis shift is Aircraft's (aircraft.py:168-187); Quadrotor's tensor is fixed
+            D.I[i][j] = I0[i][j] + (P.model_kind == ORACLE_MODEL_QUAD ? 0.0 : m * K[i][j]);
     const double (*a)[3] = D.I;
     const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
                        a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
@@ -267,6 +268,16 @@ void aero(const oracle_params& P, const Derived& D, const T x[13], const T u[7],
     a.alpha = m_atan2(a.vr[2], a.vr[0] + eps);      // base.py:176
     a.beta = m_asin(a.vr[1] / a.V);                 // base.py:234
     a.qbar = 0.5 * 1.225 * vv;                      // base.py:240
+    if (P.model_kind == ORACLE_MODEL_QUAD) {  // dynamics/quadrotor.py:43-54; moments_frd adds com x F (base.py:253-278)
+        for (int k = 0; k < 6; ++k) a.C[k] = T(0.0);
+        a.F[0] = T(0.0); a.F[1] = T(0.0);
+        a.F[2] = u[0] + u[1] + u[2] + u[3];
+        const T Mq[3] = {u[0] - u[1] - u[2] + u[3], -u[0] - u[1] + u[2] + u[3], 0.5 * (u[0] - u[1] + u[2] - u[3])};
+        a.M[0] = Mq[0] + (P.com[1] * a.F[2] - P.com[2] * a.F[1]);
+        a.M[1] = Mq[1] + (P.com[2] * a.F[0] - P.com[0] * a.F[2]);
+        a.M[2] = Mq[2] + (P.com[0] * a.F[1] - P.com[1] * a.F[0]);
+        return;
+    }
     const T da = u[0], de = u[1], dr = u[2], flaps = u[6];
 
     T C[6];

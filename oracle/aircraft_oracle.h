@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-enum { ORACLE_MODEL_DEFAULT = 0, ORACLE_MODEL_LINEAR = 1, ORACLE_MODEL_NN = 2, ORACLE_MODEL_POLY = 3 };
+enum { ORACLE_MODEL_DEFAULT = 0, ORACLE_MODEL_LINEAR = 1, ORACLE_MODEL_NN = 2, ORACLE_MODEL_POLY = 3,
+       ORACLE_MODEL_QUAD = 4 /* the Quadrotor plugin, dynamics/quadrotor.py:8-54: thrusts in control rows 0-3 */ };
 enum { ORACLE_MAX_LAYERS = 8 };
 
 typedef struct oracle_params {

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libaircraft_oracle.so")
 
-MODEL_KINDS = {"default": 0, "linear": 1, "nn": 2, "poly": 3}
+MODEL_KINDS = {"default": 0, "linear": 1, "nn": 2, "poly": 3, "quad": 4}
 MAX_LAYERS = 8
 
 

@@ -158,3 +158,45 @@ def test_per_unit_dt_and_rollout_consistency():
     for k in range(5):
         x = o.state_update(x, U[k], np.full(8, 0.01))
         assert np.array_equal(x, traj[k + 1])
+
+
+def test_quadrotor_known_answers_and_sensitivities():
+    """The Quadrotor plugin (dynamics/quadrotor.py:8-54) in the oracle: hand-computable derivative, free fall, and
+    exact AD against central differences."""
+    from oracle import Oracle
+
+    body = dict(mass=1.0, reference_area=1.0, span=1.0, chord=1.0, Ixx=1.0, Iyy=1.0, Izz=1.0, Ixz=0.0, com=[0, 0, 0])
+    o = Oracle(body, "quad", substeps=1)
+    x = np.zeros((13, 1)); x[9] = 1.0
+    u = np.zeros((7, 1)); u[:4, 0] = [1, 2, 3, 4]
+    xd = o.state_derivative(x, u)[:, 0]
+    assert np.allclose(xd[3:6], [0, 0, 10 + 9.81]) and np.allclose(xd[10:13], [1 - 2 - 3 + 4, -1 - 2 + 3 + 4, 0.5 * (1 - 2 + 3 - 4)])
+    assert not xd[:3].any() and not xd[6:10].any()
+    u[4:] = 7.0  # rows 4-6 are not controls of this plugin
+    assert np.array_equal(o.state_derivative(x, u)[:, 0], xd)
+    # free fall: RK4 is exact for constant acceleration
+    x[3:6, 0] = [1.0, -2.0, 0.5]
+    xn = o.state_update(x, np.zeros((7, 1)), 0.1)[:, 0]
+    assert np.allclose(xn[:3], [0.1, -0.2, 0.05 + 0.5 * 9.81 * 0.01], atol=1e-15) and np.allclose(xn[3:6], [1, -2, 0.5 + 0.981])
+    # off-centre reference point: moments pick up com x F (base.py:253-278)
+    body["com"] = [0.1, -0.2, 0.0]
+    oc = Oracle(body, "quad", substeps=1)
+    assert np.allclose(oc.state_derivative(np.eye(13)[:, 9:10], u)[10:13, 0] - xd[10:13], np.cross([0.1, -0.2, 0.0], [0, 0, 10.0]))
+    # sensitivities
+    rng = np.random.default_rng(3)
+    o2 = Oracle(body, "quad", substeps=2, normalise=True)
+    X = rng.normal(size=(13, 6)); X[6:10] /= np.linalg.norm(X[6:10], axis=0)
+    U = np.zeros((7, 6)); U[:4] = rng.uniform(-3, 1, (4, 6))
+    Xn, A, Bm, c = o2.step_sens(X, U, 0.02)
+    h = 1e-6
+    for j in range(13):
+        d = np.zeros((13, 1)); d[j] = h
+        fd = (o2.state_update(X + d, U, 0.02) - o2.state_update(X - d, U, 0.02)) / (2 * h)
+        assert np.abs(A[:, j] - fd).max() < 1e-7
+    for j in range(7):
+        d = np.zeros((7, 1)); d[j] = h
+        fd = (o2.state_update(X, U + d, 0.02) - o2.state_update(X, U - d, 0.02)) / (2 * h)
+        assert np.abs(Bm[:, j] - fd).max() < 1e-7
+    assert not Bm[:, 4:].any()
+    fd = (o2.state_update(X, U, 0.02 + h) - o2.state_update(X, U, 0.02 - h)) / (2 * h)
+    assert np.abs(c - fd).max() < 1e-6
