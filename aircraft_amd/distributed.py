@@ -65,6 +65,10 @@ def all_gather_records(rec, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return rec
     world = dist.get_world_size(group)
+    if rec.is_cuda and dist.get_backend(group) == "gloo":  # gloo rehearsal of the GPU path: stage through the host
+        host = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype)
+        dist.all_gather_into_tensor(host, rec.cpu(), group=group)
+        return host.to(rec.device)
     out = torch.empty((world * rec.shape[0], rec.shape[1]), device=rec.device, dtype=rec.dtype)
     dist.all_gather_into_tensor(out, rec, group=group)
     return out

@@ -84,11 +84,18 @@ def main():
     if world != args.gpus:
         log(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # rehearsal switches for a one-GPU box (never set by the driver): all ranks on cuda:0, collectives over gloo
+    backend = os.environ.get("AIRCRAFT_BENCH_BACKEND", "nccl")
+    if os.environ.get("AIRCRAFT_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from aircraft_amd import Aircraft, AircraftConfiguration, AircraftOpts, MlpData
     from aircraft_amd.control import MultipleShooting
@@ -142,7 +149,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
