@@ -67,6 +67,8 @@ PROTOTYPES = {
     "ac_step_sens_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, _VP, _VP, _VP, _VP, _VP]),
     "ac_shoot_step_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, C.c_long, _VP, _VP]),
     "ac_shoot_sens_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP, _VP]),
+    "ac_step_hess_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _VP, C.c_long, _VP, _VP]),
+    "ac_shoot_hess_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
     "ac_aero_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, _VP, _VP]),
     "ac_traj_cost_f32": (C.c_int, [_VP, _VP, C.c_long, C.c_long, _FP, C.c_float, C.c_float, _VP, _VP]),
     "ac_ilqr_backward_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP]),

@@ -111,6 +111,21 @@ class MultipleShooting:
         H = U.shape[0]
         return X[1 : H + 1] - self.propagate(X, U, dt)
 
+    def hessian(self, X, U, Lam, dt=None, out=None):
+        """Second-order blocks of every node of every instance: out (N, 21, 21, B) = sum_i Lam[k, i, b] d2F_i/dz dz at
+        (x_k, u_k, dt_k), z = (x, u, dt) — the defect rows' part of the Lagrangian Hessian (`nlp_hess_l`).
+        Lam (N, 13, B): multipliers of the defect rows (or the costate of a DDP sweep)."""
+        torch = _torch()
+        lib = self.system._sync()
+        H, B, dts, dtp, keep = self._shoot_args(X, U, dt)
+        assert Lam.shape == (H, 13, B) and Lam.is_contiguous() and Lam.dtype == torch.float32
+        if out is None:
+            out = torch.empty((H, 21, 21, B), device=X.device, dtype=torch.float32)
+        _lib.check(lib.ac_shoot_hess_f32(self.system._handle, X.data_ptr(), U.data_ptr(), dts, dtp, Lam.data_ptr(), B, H,
+                                         out.data_ptr(), self.system._stream()), "ac_shoot_hess_f32")
+        del keep
+        return out
+
     def linearise(self, X, U, dt=None, want_c=True, out=None):
         """(F, A, B, c) per node: F (N,13,B), A = dF/dx (N,13,13,B), B = dF/du (N,13,7,B), c = dF/ddt (N,13,B).
         The defect Jacobian rows are [-A_k, -B_k, I] (and -c_k * d(dt_k)/d(progress_k) in progress time)."""

@@ -1,0 +1,199 @@
+// ac_hess.hpp — second-order step sensitivities: the Hessian of  lambda . F(x, u, dt)  per unit.
+//
+// What IPOPT asks of the reference's NLP as `nlp_hess_l` (the defect rows x_{k+1} - F(x_k, u_k, dt_k) of
+// control/base.py:279-280 contribute  -lambda_k' d2F/dz2  per node; todo.md:102 names it the largest time sink).
+// Exact second-order forward mode of the same arithmetic as the step kernels: every scalar carries
+//   v, a = d/d(alpha), d[j] = d/d(beta_j), h[j] = d2/d(alpha)d(beta_j)
+// for one "outer" direction alpha and N "inner" directions beta_j.  A unit's 16 x 16 direction pairs are spread over
+// 16 * (16/N) lanes (direction layout as in SeedsT: 0-9 = v, q, omega; 10-13 = active controls; 14 = dt; 15 unused);
+// the primal is recomputed by every lane.  Analytic force models only (default / linear / poly / quadrotor); one RK4
+// sub-step (what every MPC driver of the reference uses).  d2F/dp.. = 0 and dead controls have no rows: the caller's
+// output is zero-filled and only the active 15 x 15 block is written.
+#pragma once
+#include "ac_kernels_analytic.hpp"
+
+namespace ac {
+
+template <int N> struct Jet2 {
+    float v, a, d[N], h[N];
+    AC_DI Jet2() {}
+    AC_DI Jet2(float x) : v(x), a(0.f) {  // NOLINT (implicit on purpose)
+#pragma unroll
+        for (int j = 0; j < N; ++j) { d[j] = 0.f; h[j] = 0.f; }
+    }
+};
+
+template <int N> AC_DI float value_of(const Jet2<N>& x) { return x.v; }
+
+// r = f(x) given f, f', f'' at x.v
+template <int N> AC_DI Jet2<N> jet_unary(const Jet2<N>& x, float f0, float f1, float f2) {
+    Jet2<N> r; r.v = f0; r.a = f1 * x.a;
+    const float f2a = f2 * x.a;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { r.d[j] = f1 * x.d[j]; r.h[j] = fmaf(f2a, x.d[j], f1 * x.h[j]); }
+    return r;
+}
+
+template <int N> AC_DI Jet2<N> operator+(const Jet2<N>& x, const Jet2<N>& y) {
+    Jet2<N> r; r.v = x.v + y.v; r.a = x.a + y.a;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { r.d[j] = x.d[j] + y.d[j]; r.h[j] = x.h[j] + y.h[j]; }
+    return r;
+}
+template <int N> AC_DI Jet2<N> operator-(const Jet2<N>& x, const Jet2<N>& y) {
+    Jet2<N> r; r.v = x.v - y.v; r.a = x.a - y.a;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { r.d[j] = x.d[j] - y.d[j]; r.h[j] = x.h[j] - y.h[j]; }
+    return r;
+}
+template <int N> AC_DI Jet2<N> operator-(const Jet2<N>& x) {
+    Jet2<N> r; r.v = -x.v; r.a = -x.a;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { r.d[j] = -x.d[j]; r.h[j] = -x.h[j]; }
+    return r;
+}
+template <int N> AC_DI Jet2<N> operator*(const Jet2<N>& x, const Jet2<N>& y) {
+    Jet2<N> r; r.v = x.v * y.v; r.a = fmaf(x.a, y.v, x.v * y.a);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        r.d[j] = fmaf(x.d[j], y.v, x.v * y.d[j]);
+        r.h[j] = fmaf(x.h[j], y.v, fmaf(x.a, y.d[j], fmaf(x.d[j], y.a, x.v * y.h[j])));
+    }
+    return r;
+}
+template <int N> AC_DI Jet2<N> operator*(const Jet2<N>& x, float s) {
+    Jet2<N> r; r.v = x.v * s; r.a = x.a * s;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { r.d[j] = x.d[j] * s; r.h[j] = x.h[j] * s; }
+    return r;
+}
+template <int N> AC_DI Jet2<N> operator*(float s, const Jet2<N>& x) { return x * s; }
+template <int N> AC_DI Jet2<N> operator+(const Jet2<N>& x, float s) { Jet2<N> r = x; r.v += s; return r; }
+template <int N> AC_DI Jet2<N> operator+(float s, const Jet2<N>& x) { Jet2<N> r = x; r.v += s; return r; }
+template <int N> AC_DI Jet2<N> operator-(const Jet2<N>& x, float s) { Jet2<N> r = x; r.v -= s; return r; }
+template <int N> AC_DI Jet2<N> operator-(float s, const Jet2<N>& x) { Jet2<N> r = -x; r.v += s; return r; }
+template <int N> AC_DI Jet2<N> jet_recip(const Jet2<N>& y) {
+    const float i1 = 1.0f / y.v, i2 = i1 * i1;
+    return jet_unary(y, i1, -i2, 2.0f * i2 * i1);
+}
+template <int N> AC_DI Jet2<N> operator/(const Jet2<N>& x, const Jet2<N>& y) { return x * jet_recip(y); }
+template <int N> AC_DI Jet2<N> operator/(const Jet2<N>& x, float s) { return x * (1.0f / s); }
+template <int N> AC_DI Jet2<N> operator/(float s, const Jet2<N>& y) { return jet_recip(y) * s; }
+
+template <int N> AC_DI Jet2<N> m_sqrt(const Jet2<N>& x) {
+    const float r = sqrtf(x.v), g = 0.5f / r;
+    return jet_unary(x, r, g, -0.5f * g / x.v);
+}
+template <int N> AC_DI Jet2<N> m_asin(const Jet2<N>& x) {
+    const float c2 = fmaf(-x.v, x.v, 1.0f), g = 1.0f / sqrtf(c2);
+    return jet_unary(x, asinf(x.v), g, x.v * g / c2);
+}
+template <int N> AC_DI Jet2<N> m_exp(const Jet2<N>& x) {
+    const float e = expf(x.v);
+    return jet_unary(x, e, e, e);
+}
+template <int N> AC_DI Jet2<N> m_fabs(const Jet2<N>& x) { return x.v < 0.f ? -x : x; }
+template <int N> AC_DI Jet2<N> m_atan2(const Jet2<N>& y, const Jet2<N>& x) {
+    const float i2 = 1.0f / fmaf(x.v, x.v, y.v * y.v);
+    const float ty = x.v * i2, tx = -y.v * i2;                 // d theta / dy, d theta / dx
+    const float tyy = -2.0f * x.v * y.v * i2 * i2, txx = -tyy;  // second derivatives
+    const float txy = (y.v * y.v - x.v * x.v) * i2 * i2;
+    Jet2<N> r; r.v = atan2f(y.v, x.v); r.a = fmaf(ty, y.a, tx * x.a);
+    const float ca = fmaf(tyy, y.a, txy * x.a);  // coefficient of y.d[j]
+    const float cb = fmaf(txy, y.a, txx * x.a);  // coefficient of x.d[j]
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        r.d[j] = fmaf(ty, y.d[j], tx * x.d[j]);
+        r.h[j] = fmaf(ty, y.h[j], fmaf(tx, x.h[j], fmaf(ca, y.d[j], cb * x.d[j])));
+    }
+    return r;
+}
+
+// direction -> row/column of the 21 x 21 matrix over z = (x[13], u[7], dt); -1 = no such row
+template <bool QUAD> AC_DI int hess_index(int dir) {
+    if (dir < 10) return 3 + dir;
+    if (dir < 13) return 13 + (dir - 10);
+    if (dir == 13) return QUAD ? 16 : 19;
+    if (dir == 14) return 20;
+    return -1;
+}
+
+template <int N, bool QUAD> AC_DI Jet2<N> hess_seed(int a, int g, int dir, float v, float scale = 1.f) {
+    Jet2<N> r(v);
+    r.a = (dir >= 0 && dir == a) ? scale : 0.f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) r.d[j] = (dir >= 0 && dir == N * g + j) ? scale : 0.f;
+    return r;
+}
+
+// H[za][zb][unit] = sum_i lambda_i d2F_i / dz_a dz_b, active block only (the ABI zero-fills the rest beforehand).
+template <int MODEL, int N>
+__global__ __launch_bounds__(kBlock) void k_step_hess(const DevParams P, const float* __restrict__ X,
+                                                      const float* __restrict__ U, float dt,
+                                                      const float* __restrict__ dt_per_unit,
+                                                      const float* __restrict__ Lam, long n, long blk,
+                                                      float* __restrict__ Hout) {
+    constexpr bool QUAD = MODEL == AC_MODEL_QUAD;
+    constexpr int G = 16 / N;        // inner groups
+    constexpr int LPU = 16 * G;      // lanes per unit
+    constexpr int UPB = kBlock / LPU;
+    typedef Jet2<N> T;
+    const int t = threadIdx.x % LPU;
+    const int a = t / G, g = t % G;
+    const long unit_raw = (long)blockIdx.x * UPB + threadIdx.x / LPU;
+    const bool live = unit_raw < n;
+    const long unit = live ? unit_raw : n - 1;
+    const UnitAddr ua(unit, blk);
+    float xv[13], uv[7], lam[13];
+    load_rows<13>(X, ua, xv);
+    load_rows<7>(U, ua, uv);
+    load_rows<13>(Lam, ua, lam);
+    const float hv = dt_per_unit ? dt_per_unit[unit] : dt;
+
+    T x0[13], u[7];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) x0[i] = hess_seed<N, QUAD>(a, g, i >= 3 ? i - 3 : -1, xv[i]);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int dir = QUAD ? (i < 4 ? 10 + i : -1) : ((i < 3) ? 10 + i : (i == 6 ? 13 : -1));
+        u[i] = hess_seed<N, QUAD>(a, g, dir, uv[i]);
+    }
+    const T h = hess_seed<N, QUAD>(a, g, 14, hv);
+
+    AnalyticCoeffs<MODEL> coeffs;
+    T acc[13], xs[13], k[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) { xs[i] = x0[i]; acc[i] = T(0.f); }
+#pragma nounroll
+    for (int s = 0; s < 4; ++s) {
+        state_derivative(P, coeffs, xs, u, k);
+        const float wsum = (s == 1 || s == 2) ? 2.0f : 1.0f;
+        const float cnext = (s == 2) ? 1.0f : 0.5f;
+        const T hs = h * cnext;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            acc[i] = acc[i] + wsum * k[i];
+            xs[i] = x0[i] + hs * k[i];
+        }
+    }
+    const T h6 = h * (1.0f / 6.0f);
+    T xo[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) xo[i] = x0[i] + h6 * acc[i];
+    if (P.p.normalise) normalise_q(xo);
+
+    const int za = hess_index<QUAD>(a);
+    if (!live || za < 0) return;
+    float* Hu = Hout + ua.off(441);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int zb = hess_index<QUAD>(N * g + j);
+        if (zb < 0) continue;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) s = fmaf(lam[i], xo[i].h[j], s);
+        Hu[((long)za * 21 + zb) * blk] = s;
+    }
+}
+
+}  // namespace ac

@@ -12,6 +12,7 @@
 #include "ac_nn_decl.hpp"
 #include "ac_ilqr.hpp"
 #include "ac_track.hpp"
+#include "ac_hess.hpp"
 
 using namespace ac;
 
@@ -95,6 +96,18 @@ template <class K> int set_lds_limit(K kernel, int bytes) {
     if (bytes > 64 * 1024) AC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     return AC_OK;
+}
+
+template <int MODEL> struct HessN { static constexpr int value = (MODEL == AC_MODEL_POLY) ? 2 : 4; };
+
+template <int MODEL>
+void launch_hess(ac_handle* h, hipStream_t st, const float* X, const float* U, float dt, const float* dt_per_unit,
+                        const float* Lam, long n, long blk, float* Hout, int* grid_out) {
+    constexpr int N = HessN<MODEL>::value;
+    constexpr int upb = kBlock / (16 * (16 / N));  // units per workgroup
+    const int grid = (int)((n + upb - 1) / upb);
+    hipLaunchKernelGGL((k_step_hess<MODEL, N>), grid, kBlock, 0, st, h->dp, X, U, dt, dt_per_unit, Lam, n, blk, Hout);
+    *grid_out = grid;
 }
 
 // ---- dispatch helpers --------------------------------------------------------------------------
@@ -492,6 +505,39 @@ int ac_shoot_sens_f32(ac_handle* h, const float* X, const float* U, float dt, co
                       float* Xn, float* A, float* Bm, float* c, void* stream) {
     if (B < 0 || H < 0) return AC_ERR_BAD_ARG;
     return sens_impl(h, X, U, dt, dt_per_unit, B * H, B, Xn, A, Bm, c, stream);
+}
+
+// ---- second-order step sensitivities ---------------------------------------------------------------
+static int hess_impl(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, const float* Lam,
+                     long n, long blk, float* Hout, void* stream) {
+    if (h && n == 0) return AC_OK;
+    if (!h || !X || !U || !Lam || !Hout || n < 0 || blk <= 0) return AC_ERR_BAD_ARG;
+    if (h->dp.p.model_kind == AC_MODEL_NN || h->dp.p.substeps != 1) return AC_ERR_UNSUPPORTED;
+    int rc = model_ready(h);
+    if (rc != AC_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    AC_HIP(hipMemsetAsync(Hout, 0, (size_t)n * 441 * sizeof(float), st));
+    int grid = 0;
+    switch (h->dp.p.model_kind) {
+        case AC_MODEL_LINEAR: launch_hess<AC_MODEL_LINEAR>(h, st, X, U, dt, dt_per_unit, Lam, n, blk, Hout, &grid); break;
+        case AC_MODEL_POLY: launch_hess<AC_MODEL_POLY>(h, st, X, U, dt, dt_per_unit, Lam, n, blk, Hout, &grid); break;
+        case AC_MODEL_QUAD: launch_hess<AC_MODEL_QUAD>(h, st, X, U, dt, dt_per_unit, Lam, n, blk, Hout, &grid); break;
+        default: launch_hess<AC_MODEL_DEFAULT>(h, st, X, U, dt, dt_per_unit, Lam, n, blk, Hout, &grid); break;
+    }
+    note_launch(h, "k_step_hess", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_step_hess_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit,
+                     const float* lambda, long n, float* Hout, void* stream) {
+    return hess_impl(h, X, U, dt, dt_per_unit, lambda, n, n > 0 ? n : 1, Hout, stream);
+}
+
+int ac_shoot_hess_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit,
+                      const float* lambda, long B, long H, float* Hout, void* stream) {
+    if (B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    return hess_impl(h, X, U, dt, dt_per_unit, lambda, B * H, B > 0 ? B : 1, Hout, stream);
 }
 
 int ac_traj_cost_f32(ac_handle* h, const float* X, long B, long H, const float* goal3, float w_track, float w_goal,

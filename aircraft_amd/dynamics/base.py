@@ -283,6 +283,27 @@ class SixDOF(ABC):
             c = None if c is None else c[..., 0]
         return Xn, A, Bm, c
 
+    def step_hess(self, x, u, dt, lam, out=None):
+        """Hessian of lam . F(x, u, dt) over z = (x[13], u[7], dt): (21, 21, n) — the block the defect rows contribute to
+        the Lagrangian Hessian IPOPT evaluates as `nlp_hess_l` (control/base.py:279-280; todo.md:102).
+        lam (13, n): multipliers of the rows of F.  Analytic force models and one RK4 sub-step only."""
+        lib = self._sync()
+        torch = _torch()
+        X, npx, vec = self._in(x, self.num_states, "x")
+        U, _, _ = self._in_u(u)
+        L, _, _ = self._in(lam, self.num_states, "lam")
+        n = X.shape[1]
+        if U.shape[1] != n or L.shape[1] != n:
+            raise ValueError("x, u and lam must have the same number of columns")
+        dts, dtp, keep = self._dt_args(dt, n)
+        if out is None:
+            out = torch.empty((21, 21, n), device=X.device, dtype=torch.float32)
+        _lib.check(lib.ac_step_hess_f32(self._handle, X.data_ptr(), U.data_ptr(), dts, dtp, L.data_ptr(), n,
+                                        out.data_ptr(), self._stream()), "ac_step_hess_f32")
+        del keep
+        res = out.cpu().numpy().astype(np.float64) if npx else out
+        return res[..., 0] if vec else res
+
     # ---- getters (reference dynamics/base.py:147-278, aircraft.py:255-330) ------------------------
     def _aero(self, x, u):
         lib = self._sync()

@@ -127,6 +127,18 @@ int ac_shoot_step_f32(ac_handle* h, const float* X, const float* U, float dt, co
 int ac_shoot_sens_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long B,
                       long H, float* Xn, float* A, float* Bm, float* c, void* stream);
 
+/* Second-order step sensitivities: Hout [21][21][n] = sum_i lambda_i d2F_i / dz dz over z = (x[13], u[7], dt) — the
+ * block the defect rows x_{k+1} - F(x_k, u_k, dt_k) (control/base.py:279-280) contribute to IPOPT's `nlp_hess_l`
+ * (the reference's largest time sink, todo.md:102).  lambda [13][n] (device) are the multipliers of the 13 rows of F.
+ * Exact second-order forward mode of the same fp32 arithmetic as ac_step_f32.  Rows/columns of p (0-2) and of controls
+ * without effect are zero.  Analytic force models only (default / linear / poly / quadrotor) and substeps == 1;
+ * AC_ERR_UNSUPPORTED otherwise.  ac_shoot_hess_f32 reads rollout-shaped X [H(+1)][13][B], U [H][7][B],
+ * lambda [H][13][B] in place and writes Hout [H][21][21][B]. */
+int ac_step_hess_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit,
+                     const float* lambda, long n, float* Hout, void* stream);
+int ac_shoot_hess_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit,
+                      const float* lambda, long B, long H, float* Hout, void* stream);
+
 /* Getters, out [22][n]: v_frd_rel(3), airspeed, alpha, beta, qbar, coefficients(6), forces_frd(3), moments_frd(3),
  * phi, theta, psi (Euler angles of q)        — dynamics/base.py:147-278, dynamics/aircraft.py:255-330, base.py:179-195 */
 int ac_aero_f32(ac_handle* h, const float* X, const float* U, long n, float* out, void* stream);

@@ -133,3 +133,27 @@ def well_conditioned(orc, X0, U, dt, eps=1e-7, tol=1e-6, seed=0, rollout=True):
         sane = (np.abs(ref[..., 3:6, :]).reshape(-1, ref.shape[-1]).max(axis=0) < 150.0) & \
                (np.abs(ref[..., 10:13, :]).reshape(-1, ref.shape[-1]).max(axis=0) < 20.0)
     return (worst < tol) & fin & sane, ref
+
+
+def oracle_step_hessian(orc, X, U, dt, lam, h=1e-5):
+    """(21, 21, n): Hessian of lam . F over z = (x, u, dt) by central differences of the oracle's EXACT float64
+    Jacobians [A | B | c] (truncation ~h^2, round-off ~1e-16/h: about 1e-9 relative)."""
+    n = X.shape[1]
+    dtv = np.full(n, float(dt)) if np.ndim(dt) == 0 else np.asarray(dt, dtype=np.float64)
+
+    def grad(Xq, Uq, dtq):
+        _, A, Bm, c = orc.step_sens(Xq, Uq, dtq)
+        J = np.concatenate([A, Bm, c[:, None, :]], axis=1)  # (13, 21, n)
+        return np.einsum("in,izn->zn", lam, J)
+
+    Hm = np.zeros((21, 21, n))
+    for a in range(21):
+        dX, dU, dd = np.zeros_like(X), np.zeros_like(U), np.zeros(n)
+        if a < 13:
+            dX[a] = h
+        elif a < 20:
+            dU[a - 13] = h
+        else:
+            dd[:] = h
+        Hm[a] = (grad(X + dX, U + dU, dtv + dd) - grad(X - dX, U - dU, dtv - dd)) / (2 * h)
+    return Hm

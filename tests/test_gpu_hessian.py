@@ -1,0 +1,109 @@
+"""GPU tests of the second-order step sensitivities: Hessian of lambda . F(x, u, dt) per unit against
+central differences of the oracle's exact float64 Jacobians."""
+import numpy as np
+import pytest
+
+from tests.helpers import f32_exact, make_aircraft, make_oracle, oracle_step_hessian, synthetic_units
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, gpu):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(gpu)
+
+
+def rel_block(got, want):
+    """max over units of ||got - want||_F / ||want||_F"""
+    num = np.sqrt(((got - want) ** 2).sum(axis=(0, 1)))
+    den = np.sqrt((want ** 2).sum(axis=(0, 1)))
+    return float((num / np.maximum(den, 1e-30)).max())
+
+
+def units(n, seed):
+    X, U = synthetic_units(n, seed=seed, flaps=True)
+    rng = np.random.default_rng(seed + 100)
+    lam = f32_exact(rng.normal(size=(13, n)))
+    return X, U, lam
+
+
+@pytest.mark.parametrize("model,normalise", [("default", False), ("default", True), ("linear", True), ("poly", False),
+                                             ("poly", True)])
+def test_hessian_matches_finite_differences_of_exact_jacobians(gpu, model, normalise):
+    ac = make_aircraft(model, normalise=normalise, stall_scaling=(model == "default"))
+    orc = make_oracle(ac)
+    X, U, lam = units(96, seed=31)
+    Hm = ac.step_hess(dev(X, gpu), dev(U, gpu), 0.01, dev(lam, gpu)).cpu().numpy().astype(np.float64)
+    want = oracle_step_hessian(orc, X, U, 0.01, lam)
+    assert Hm.shape == (21, 21, 96)
+    assert rel_block(Hm, want) < 2e-4
+    # structure: symmetric (every (a, b) pair is computed on its own lane), zero rows for position and the thrust controls
+    assert np.abs(Hm - Hm.transpose(1, 0, 2)).max() <= 1e-5 * np.abs(Hm).max()
+    for z in (0, 1, 2, 16, 17, 18):
+        assert not Hm[z].any() and not Hm[:, z].any()
+    assert np.abs(want[[0, 1, 2, 16, 17, 18]]).max() < 1e-6 * np.abs(want).max()
+
+
+def test_hessian_per_unit_dt_and_numpy_vector(gpu):
+    ac = make_aircraft("poly", normalise=True)
+    orc = make_oracle(ac)
+    X, U, lam = units(40, seed=33)
+    dts = f32_exact(np.random.default_rng(2).uniform(0.005, 0.02, 40))
+    Hm = ac.step_hess(dev(X, gpu), dev(U, gpu), dev(dts, gpu), dev(lam, gpu)).cpu().numpy().astype(np.float64)
+    assert rel_block(Hm, oracle_step_hessian(orc, X, U, dts, lam)) < 2e-4
+    one = ac.step_hess(X[:, 3], U[:, 3], float(dts[3]), lam[:, 3])  # numpy vectors in -> (21, 21) float64 out
+    assert one.shape == (21, 21) and np.allclose(one, Hm[:, :, 3], rtol=0, atol=1e-6 * np.abs(Hm[:, :, 3]).max())
+
+
+def test_hessian_quadrotor(gpu):
+    from aircraft_amd import Quadrotor
+    from oracle import Oracle
+    from tests.test_gpu_quadrotor import pad7, quad_units
+
+    q = Quadrotor()
+    q.normalise = True
+    q.com = np.array([0.02, -0.01, 0.03])
+    orc = Oracle(q.airframe_dict(), "quad", None, substeps=1, normalise=True, epsilon=q.epsilon, gravity=q.gravity)
+    X, U = quad_units(64, seed=9)
+    lam = f32_exact(np.random.default_rng(3).normal(size=(13, 64)))
+    Hm = q.step_hess(dev(X, gpu), dev(U, gpu), 0.02, dev(lam, gpu)).cpu().numpy().astype(np.float64)
+    want = oracle_step_hessian(orc, X, pad7(U), 0.02, lam)
+    assert rel_block(Hm, want) < 2e-4
+    for z in (0, 1, 2, 17, 18, 19):  # position, and the three control rows this plugin does not have
+        assert not Hm[z].any() and not Hm[:, z].any()
+    assert np.abs(Hm[13:17, 13:17]).max() > 0  # thrust-thrust curvature comes from the normalisation and RK4 coupling
+
+
+def test_shooting_hessian_in_place_equals_flat_call(gpu):
+    import torch
+    from aircraft_amd.control import MultipleShooting
+    from aircraft_amd.synthetic import synthetic_problem
+
+    ac = make_aircraft("poly", normalise=True)
+    B, H = 24, 5
+    X0, U = synthetic_problem(B, H, seed=23)
+    ms = MultipleShooting(system=ac, dt=0.01, num_nodes=H, opts={"quaternion": "integration"})
+    Ud = dev(U, gpu)
+    Xt = ms.rollout(dev(X0, gpu), Ud)
+    Lam = dev(np.random.default_rng(5).normal(size=(H, 13, B)), gpu)
+    Hs = ms.hessian(Xt, Ud, Lam)
+    assert Hs.shape == (H, 21, 21, B)
+    flatX = Xt[:H].permute(1, 0, 2).reshape(13, H * B).contiguous()
+    flatU = Ud.permute(1, 0, 2).reshape(7, H * B).contiguous()
+    flatL = Lam.permute(1, 0, 2).reshape(13, H * B).contiguous()
+    Hf = ac.step_hess(flatX, flatU, 0.01, flatL)
+    assert torch.equal(Hs.permute(1, 2, 0, 3).reshape(21, 21, H * B), Hf)
+
+
+def test_hessian_unsupported_cases_fail_loudly(gpu):
+    from aircraft_amd import AircraftHipError
+
+    X, U, lam = units(8, seed=1)
+    nn = make_aircraft("nn", hidden=(32, 32))
+    with pytest.raises(AircraftHipError, match="UNSUPPORTED"):
+        nn.step_hess(dev(X, gpu), dev(U, gpu), 0.01, dev(lam, gpu))
+    ac = make_aircraft("poly")
+    ac.physical_integration_substeps = 2
+    with pytest.raises(AircraftHipError, match="UNSUPPORTED"):
+        ac.step_hess(dev(X, gpu), dev(U, gpu), 0.01, dev(lam, gpu))
