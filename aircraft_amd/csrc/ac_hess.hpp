@@ -150,36 +150,43 @@ __global__ __launch_bounds__(kBlock) void k_step_hess(const DevParams P, const f
     load_rows<13>(Lam, ua, lam);
     const float hv = dt_per_unit ? dt_per_unit[unit] : dt;
 
-    T x0[13], u[7];
-#pragma unroll
-    for (int i = 0; i < 13; ++i) x0[i] = hess_seed<N, QUAD>(a, g, i >= 3 ? i - 3 : -1, xv[i]);
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const int dir = QUAD ? (i < 4 ? 10 + i : -1) : ((i < 3) ? 10 + i : (i == 6 ? 13 : -1));
-        u[i] = hess_seed<N, QUAD>(a, g, dir, uv[i]);
-    }
-    const T h = hess_seed<N, QUAD>(a, g, 14, hv);
-
+    // The seeds are 0/1 patterns of (a, g): they are rebuilt where they are used instead of being carried through the
+    // RK4 loop (13 + 7 jets of registers otherwise), with the lane ids hidden from loop-invariant hoisting.
+    auto seed_x = [&](int aa, int gg, int i) { return hess_seed<N, QUAD>(aa, gg, i >= 3 ? i - 3 : -1, xv[i]); };
     AnalyticCoeffs<MODEL> coeffs;
     T acc[13], xs[13], k[13];
 #pragma unroll
-    for (int i = 0; i < 13; ++i) { xs[i] = x0[i]; acc[i] = T(0.f); }
+    for (int i = 0; i < 13; ++i) { xs[i] = seed_x(a, g, i); acc[i] = T(0.f); }
 #pragma nounroll
     for (int s = 0; s < 4; ++s) {
-        state_derivative(P, coeffs, xs, u, k);
+        int aa = a, gg = g;
+        asm volatile("" : "+v"(aa), "+v"(gg));
+        {
+            T u[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const int dir = QUAD ? (i < 4 ? 10 + i : -1) : ((i < 3) ? 10 + i : (i == 6 ? 13 : -1));
+                u[i] = hess_seed<N, QUAD>(aa, gg, dir, uv[i]);
+            }
+            state_derivative(P, coeffs, xs, u, k);
+        }
         const float wsum = (s == 1 || s == 2) ? 2.0f : 1.0f;
         const float cnext = (s == 2) ? 1.0f : 0.5f;
-        const T hs = h * cnext;
+        const T hs = hess_seed<N, QUAD>(aa, gg, 14, hv * cnext, cnext);
 #pragma unroll
         for (int i = 0; i < 13; ++i) {
             acc[i] = acc[i] + wsum * k[i];
-            xs[i] = x0[i] + hs * k[i];
+            xs[i] = seed_x(aa, gg, i) + hs * k[i];
         }
     }
-    const T h6 = h * (1.0f / 6.0f);
     T xo[13];
+    {
+        int aa = a, gg = g;
+        asm volatile("" : "+v"(aa), "+v"(gg));
+        const T h6 = hess_seed<N, QUAD>(aa, gg, 14, hv * (1.0f / 6.0f), 1.0f / 6.0f);
 #pragma unroll
-    for (int i = 0; i < 13; ++i) xo[i] = x0[i] + h6 * acc[i];
+        for (int i = 0; i < 13; ++i) xo[i] = seed_x(aa, gg, i) + h6 * acc[i];
+    }
     if (P.p.normalise) normalise_q(xo);
 
     const int za = hess_index<QUAD>(a);

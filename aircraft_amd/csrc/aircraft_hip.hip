@@ -98,7 +98,13 @@ template <class K> int set_lds_limit(K kernel, int bytes) {
     return AC_OK;
 }
 
-template <int MODEL> struct HessN { static constexpr int value = (MODEL == AC_MODEL_POLY) ? 2 : 4; };
+#ifndef AC_HESS_N_POLY
+#define AC_HESS_N_POLY 1
+#endif
+#ifndef AC_HESS_N_OTHER
+#define AC_HESS_N_OTHER 2
+#endif
+template <int MODEL> struct HessN { static constexpr int value = (MODEL == AC_MODEL_POLY) ? AC_HESS_N_POLY : AC_HESS_N_OTHER; };
 
 template <int MODEL>
 void launch_hess(ac_handle* h, hipStream_t st, const float* X, const float* U, float dt, const float* dt_per_unit,
