@@ -75,6 +75,9 @@ PROTOTYPES = {
     "ac_ilqr_cost_f32": (C.c_int, [_VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
     "ac_ilqr_backward_node_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP,
                                             _VP]),
+    "ac_ilqr_costate_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
+    "ac_ilqr_backward_newton_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP,
+                                              _VP, _VP, _VP]),
     "ac_ilqr_cost_node_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_long, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
     "ac_set_track": (C.c_int, [_VP, C.c_int, _FP, C.c_float]),
     "ac_track_eval_f32": (C.c_int, [_VP, _VP, C.c_long, _VP, _VP, _VP]),

@@ -64,11 +64,14 @@ class QuadraticCost:
 
 class ILQR(MultipleShooting):
     def __init__(self, *, system, dt: float = 0.01, num_nodes: int, cost: QuadraticCost, opts: Optional[dict] = None,
-                 alphas: Sequence[float] = (1.0, 0.5, 0.25, 0.1, 0.03)):
+                 alphas: Sequence[float] = (1.0, 0.5, 0.25, 0.1, 0.03), hessian: str = "gauss-newton"):
+        """hessian: 'gauss-newton' (first-order dynamics in the backward pass: iLQR) or 'exact' (adds the second-order
+        terms  sum_i lambda_i d2F_i/dz dz  of every node — what IPOPT gets from `nlp_hess_l`; analytic force models)."""
         super().__init__(system=system, dt=dt, num_nodes=num_nodes, opts=opts or {"quaternion": "integration"})
-        assert 1 <= len(alphas) <= 8
+        assert 1 <= len(alphas) <= 8 and hessian in ("gauss-newton", "exact")
         self.cost = cost
         self.alphas = [float(a) for a in alphas]
+        self.hessian_mode = hessian
         self._ws = None
 
     # ---- device workspace (allocated once per (B, H)) ------------------------------------------------
@@ -80,6 +83,8 @@ class ILQR(MultipleShooting):
             f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)  # noqa: E731
             self._ws = dict(key=key, F=f(H, 13, B), A=f(H, 13, 13, B), Bm=f(H, 13, 7, B), K=f(H, 7, 13, B), kff=f(H, 7, B),
                             dV=f(2, B), Xc=f(H + 1, 13, na * B), Uc=f(H, 7, na * B), Jc=f(na * B), J0=f(B))
+            if self.hessian_mode == "exact":
+                self._ws.update(Lam=f(H, 13, B), Hz=f(H, 21, 21, B))
         return self._ws
 
     def _cstruct(self):
@@ -95,17 +100,45 @@ class ILQR(MultipleShooting):
                                         out.data_ptr(), self.system._stream()), "ac_ilqr_cost_f32")
         return out
 
-    def backward(self, X, U, A, Bm, out=None):
+    def _node_cost(self, X, U):
+        """Hook: per-node state-cost arrays (node_q, node_xref, node_glin), each (N+1, 13, B), or None for the constant
+        quadratic cost of `self.cost` (MHTT overrides this)."""
+        return None
+
+    @staticmethod
+    def _ptrs(node):
+        return [C.c_void_p(t.data_ptr()) for t in node] if node is not None else [C.c_void_p(0)] * 3
+
+    def costate(self, X, A, node=None, out=None):
+        """Multipliers of the defect rows at the current iterate, (N, 13, B): Lam[N-1] = grad l_N(x_N),
+        Lam[k-1] = grad l_k(x_k) + A_k' Lam[k]."""
+        torch = _torch()
+        lib = self.system._sync()
+        H, B = A.shape[0], A.shape[3]
+        if out is None:
+            out = torch.empty((H, 13, B), device=X.device, dtype=torch.float32)
+        _lib.check(lib.ac_ilqr_costate_f32(self.system._handle, self._cstruct(), *self._ptrs(node), X.data_ptr(),
+                                           A.data_ptr(), B, H, out.data_ptr(), self.system._stream()),
+                   "ac_ilqr_costate_f32")
+        return out
+
+    def backward(self, X, U, A, Bm, out=None, Hz=None, node="auto"):
+        """Riccati pass -> K (N, 7, 13, B), kff (N, 7, B), dV (2, B).  Hz (N, 21, 21, B): optional second-order
+        dynamics blocks from `hessian()` (exact-Hessian / Newton step)."""
         torch = _torch()
         lib = self.system._sync()
         H, B = U.shape[0], U.shape[2]
+        if isinstance(node, str):
+            node = self._node_cost(X, U)
         if out is None:
             out = (torch.empty((H, 7, 13, B), device=X.device), torch.empty((H, 7, B), device=X.device),
                    torch.empty((2, B), device=X.device))
         K, kff, dV = out
-        _lib.check(lib.ac_ilqr_backward_f32(self.system._handle, self._cstruct(), X.data_ptr(), U.data_ptr(),
-                                            A.data_ptr(), Bm.data_ptr(), B, H, K.data_ptr(), kff.data_ptr(),
-                                            dV.data_ptr(), self.system._stream()), "ac_ilqr_backward_f32")
+        _lib.check(lib.ac_ilqr_backward_newton_f32(self.system._handle, self._cstruct(), *self._ptrs(node),
+                                                   C.c_void_p(Hz.data_ptr() if Hz is not None else 0), X.data_ptr(),
+                                                   U.data_ptr(), A.data_ptr(), Bm.data_ptr(), B, H, K.data_ptr(),
+                                                   kff.data_ptr(), dV.data_ptr(), self.system._stream()),
+                   "ac_ilqr_backward_newton_f32")
         return K, kff, dV
 
     def forward(self, x0, Xnom, U, K, kff, alphas=None, out=None):
@@ -132,7 +165,12 @@ class ILQR(MultipleShooting):
         ws = self._workspace(B, U.device)
         na = len(self.alphas)
         self.linearise(X, U, want_c=False, out=(ws["F"], ws["A"], ws["Bm"], None))
-        self.backward(X, U, ws["A"], ws["Bm"], out=(ws["K"], ws["kff"], ws["dV"]))
+        node = self._node_cost(X, U)
+        Hz = None
+        if self.hessian_mode == "exact":
+            self.costate(X, ws["A"], node, out=ws["Lam"])
+            Hz = self.hessian(X, U, ws["Lam"], out=ws["Hz"])
+        self.backward(X, U, ws["A"], ws["Bm"], out=(ws["K"], ws["kff"], ws["dV"]), Hz=Hz, node=node)
         self.forward(x0, X, U, ws["K"], ws["kff"], out=(ws["Xc"], ws["Uc"]))
         self.trajectory_cost(ws["Xc"], ws["Uc"], out=ws["Jc"])
         self.trajectory_cost(X, U, out=ws["J0"])

@@ -258,21 +258,11 @@ class MHTT(ILQR):
             S = self.progress(X, ws["s0c"], mode=1, out=ws["Sc"])
         return self.loss(X, U, S, out=out)
 
-    def backward(self, X, U, A, Bm, out=None):
-        torch = _torch()
-        lib = self.system._sync()
-        H, B = U.shape[0], U.shape[2]
-        ws = self._mhtt_workspace(B, U.device)
+    def _node_cost(self, X, U):
+        """The frozen-progress quadratic model of the MHTT loss around (X, U), written by the progress kernel."""
+        ws = self._mhtt_workspace(U.shape[2], U.device)
         self.progress(X, self.s0, mode=1, model=(ws["nq"], ws["nx"], ws["ng"]), out=ws["S"])
-        if out is None:
-            out = (torch.empty((H, 7, 13, B), device=X.device), torch.empty((H, 7, B), device=X.device),
-                   torch.empty((2, B), device=X.device))
-        K, kff, dV = out
-        _lib.check(lib.ac_ilqr_backward_node_f32(self.system._handle, self._cstruct(), ws["nq"].data_ptr(),
-                                                 ws["nx"].data_ptr(), ws["ng"].data_ptr(), X.data_ptr(), U.data_ptr(),
-                                                 A.data_ptr(), Bm.data_ptr(), B, H, K.data_ptr(), kff.data_ptr(),
-                                                 dV.data_ptr(), self.system._stream()), "ac_ilqr_backward_node_f32")
-        return K, kff, dV
+        return ws["nq"], ws["nx"], ws["ng"]
 
     def advance_progress(self, X, keep: int):
         """Receding-horizon shift: s0 <- progress reached at node `keep` of the accepted trajectory (mhtt.py:87, 105)."""

@@ -59,7 +59,7 @@ constexpr int kIlqrFloats = 1024;  // LDS floats per instance (layout below)
 template <int kUnused = 0>  // template: this header is included by several translation units
 __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const NodeCost N, const float* __restrict__ X,
                                                       const float* __restrict__ U, const float* __restrict__ A,
-                                                      const float* __restrict__ Bm, long B, long H,
+                                                      const float* __restrict__ Bm, const float* __restrict__ Hz, long B, long H,
                                                       float* __restrict__ K, float* __restrict__ kff,
                                                       float* __restrict__ dV) {
     __shared__ float smem[4 * kIlqrFloats];
@@ -131,13 +131,16 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const No
         if (j < 13) {
             qx = sqx[j];
             for (int m = 0; m < 13; ++m) qx = fmaf(sA[m * 13 + j], svx[m], qx);
+            // Hz (optional): second-order dynamics terms  sum_i lambda_i d2F_i/dz dz  of this node, z = (x, u, dt)
+            const float* hz = Hz ? Hz + (k * 441) * B + b : nullptr;
             for (int i = 0; i < 13; ++i) {
                 float s = (i == j) ? qjj : 0.f;
+                if (hz) s += hz[((long)i * 21 + j) * B];
                 for (int m = 0; m < 13; ++m) s = fmaf(sA[m * 13 + i], sVA[m * 13 + j], s);
                 qxx[i] = s;
             }
             for (int i = 0; i < 7; ++i) {
-                float s = 0.f;
+                float s = hz ? hz[((long)(13 + i) * 21 + j) * B] : 0.f;
                 for (int m = 0; m < 13; ++m) s = fmaf(sB[m * 7 + i], sVA[m * 13 + j], s);
                 sQux[i * 13 + j] = s;
             }
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const No
             squ[j] = qu;  // now holds Qu
             for (int i = 0; i < 7; ++i) {
                 float s = (i == j) ? C.r[j] + C.reg : 0.f;
+                if (Hz) s += Hz[((k * 21 + 13 + i) * 21 + 13 + j) * B + b];
                 for (int m = 0; m < 13; ++m) s = fmaf(sB[m * 7 + i], sVB[m * 7 + j], s);
                 sQuu[i * 7 + j] = s;
             }
@@ -232,6 +236,42 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const No
         __syncthreads();
     }
     if (live && j == 0) { dV[b] = dv1; dV[B + b] = dv2; }
+}
+
+// ---- costate sweep ------------------------------------------------------------------------------------
+// Multipliers of the defect rows x_{k+1} = F(x_k, u_k) at the current iterate (the NLP's lambda estimate):
+//   Lam[H-1] = grad l_N(x_N),   Lam[k-1] = grad l_k(x_k) + A_k' Lam[k]
+// One lane per instance, sequential in k; feeds ac_shoot_hess_f32 for the exact-Hessian (Newton) backward pass.
+template <int kUnused = 0>
+__global__ __launch_bounds__(kBlock) void k_ilqr_costate(const IlqrCost C, const NodeCost N, const float* __restrict__ X,
+                                                         const float* __restrict__ A, long B, long H,
+                                                         float* __restrict__ Lam) {
+    const long b = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (b >= B) return;
+    float lam[13];
+#pragma unroll
+    for (int j = 0; j < 13; ++j) {
+        float qj, xr, gl;
+        N.row(C, H, true, j, b, qj, xr, gl);
+        lam[j] = fmaf(qj, X[(H * 13 + j) * B + b] - xr, gl);
+    }
+    for (long k = H - 1;; --k) {
+#pragma unroll
+        for (int j = 0; j < 13; ++j) Lam[(k * 13 + j) * B + b] = lam[j];
+        if (k == 0) break;
+        float nxt[13];
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+            float qj, xr, gl;
+            N.row(C, k, false, j, b, qj, xr, gl);
+            float s = fmaf(qj, X[(k * 13 + j) * B + b] - xr, gl);
+#pragma unroll
+            for (int m = 0; m < 13; ++m) s = fmaf(A[((k * 13 + m) * 13 + j) * B + b], lam[m], s);
+            nxt[j] = s;
+        }
+#pragma unroll
+        for (int j = 0; j < 13; ++j) lam[j] = nxt[j];
+    }
 }
 
 // ---- quadratic trajectory cost ---------------------------------------------------------------------

@@ -573,13 +573,34 @@ int ac_ilqr_backward_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* X,
 int ac_ilqr_backward_node_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* node_q, const float* node_xref,
                               const float* node_glin, const float* X, const float* U, const float* A, const float* Bm,
                               long B, long H, float* K, float* kff, float* dV, void* stream) {
+    return ac_ilqr_backward_newton_f32(h, cost, node_q, node_xref, node_glin, nullptr, X, U, A, Bm, B, H, K, kff, dV,
+                                       stream);
+}
+
+int ac_ilqr_costate_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* node_q, const float* node_xref,
+                        const float* node_glin, const float* X, const float* A, long B, long H, float* Lam,
+                        void* stream) {
+    if (h && B == 0) return AC_OK;
+    if (!h || !cost || !X || !A || !Lam || B < 0 || H < 1) return AC_ERR_BAD_ARG;
+    if ((node_q || node_xref || node_glin) && !(node_q && node_xref && node_glin)) return AC_ERR_BAD_ARG;
+    const NodeCost nc{node_q, node_xref, node_glin, B};
+    const int grid = (int)((B + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_ilqr_costate<0>, grid, kBlock, 0, (hipStream_t)stream, to_dev_cost(cost), nc, X, A, B, H, Lam);
+    note_launch(h, "k_ilqr_costate", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_ilqr_backward_newton_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* node_q, const float* node_xref,
+                                const float* node_glin, const float* Hz, const float* X, const float* U, const float* A,
+                                const float* Bm, long B, long H, float* K, float* kff, float* dV, void* stream) {
     if (h && B == 0) return AC_OK;
     if (!h || !cost || !X || !U || !A || !Bm || !K || !kff || !dV || B < 0 || H < 1) return AC_ERR_BAD_ARG;
     if ((node_q || node_xref || node_glin) && !(node_q && node_xref && node_glin)) return AC_ERR_BAD_ARG;
     const NodeCost nc{node_q, node_xref, node_glin, B};
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)((B + 3) / 4);
-    hipLaunchKernelGGL(k_ilqr_backward<0>, grid, 64, 0, st, to_dev_cost(cost), nc, X, U, A, Bm, B, H, K, kff, dV);
+    hipLaunchKernelGGL(k_ilqr_backward<0>, grid, 64, 0, st, to_dev_cost(cost), nc, X, U, A, Bm, Hz, B, H, K, kff, dV);
     note_launch(h, "k_ilqr_backward", grid, 64, 4 * kIlqrFloats * 4);
     AC_HIP(hipGetLastError());
     return AC_OK;

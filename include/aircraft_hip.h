@@ -185,6 +185,19 @@ int ac_ilqr_cost_node_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* n
                           const float* node_glin, long Bn, const float* X, const float* U, long B, long H, float* out,
                           void* stream);
 
+/* Exact-Hessian (Newton / SQP) variant of the sweep, for the force models ac_shoot_hess_f32 supports:
+ *   ac_ilqr_costate_f32        Lam [H][13][B]: multipliers of the defect rows at the current iterate,
+ *                              Lam[H-1] = grad l_N(x_N), Lam[k-1] = grad l_k(x_k) + A_k' Lam[k]
+ *   ac_shoot_hess_f32          Hz [H][21][21][B] = sum_i Lam[k][i] d2F_i/dz dz      (the nlp_hess_l blocks)
+ *   ac_ilqr_backward_newton_f32  the backward pass with Hz's (x,x), (u,x), (u,u) blocks added to Qxx, Qux, Quu
+ * node_q/node_xref/node_glin and Hz may be NULL (then this is ac_ilqr_backward_f32). */
+int ac_ilqr_costate_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* node_q, const float* node_xref,
+                        const float* node_glin, const float* X, const float* A, long B, long H, float* Lam,
+                        void* stream);
+int ac_ilqr_backward_newton_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* node_q, const float* node_xref,
+                                const float* node_glin, const float* Hz, const float* X, const float* U, const float* A,
+                                const float* Bm, long B, long H, float* K, float* kff, float* dV, void* stream);
+
 /* ---- track + progress terms of the moving-horizon track tracker   ---------------------------
  * Track: piecewise cubic Hermite curve over s in [0,1] through the sampled Dubins path
  * (control/initialisation.py:782-851).  `coef` is a HOST array [n_segments][3][4]: per segment and axis the cubic

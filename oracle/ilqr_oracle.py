@@ -20,8 +20,31 @@ def cost(c, X, U, node=None):
         0.5 * (qf[:, None] * dg * dg).sum(axis=0)
 
 
-def backward(c, X, U, A, Bm, node=None):
-    """A (H,13,13,B), Bm (H,13,7,B) -> K (H,7,13,B), kff (H,7,B), dV (2,B)"""
+def costate(c, X, A, node=None):
+    """Multipliers of the defect rows: Lam[H-1] = grad l_N(x_N), Lam[k-1] = grad l_k(x_k) + A_k' Lam[k] -> (H,13,B)"""
+    H, B = A.shape[0], A.shape[3]
+    q, qf = np.asarray(c.q, float), np.asarray(c.qf, float)
+    Lam = np.zeros((H, 13, B))
+    for b in range(B):
+        if node is None:
+            lam = qf * (X[H, :, b] - np.asarray(c.x_goal))
+        else:
+            lam = node[0][H, :, b] * (X[H, :, b] - node[1][H, :, b]) + node[2][H, :, b]
+        for k in range(H - 1, -1, -1):
+            Lam[k, :, b] = lam
+            if k == 0:
+                break
+            if node is None:
+                lx = q * (X[k, :, b] - np.asarray(c.x_ref))
+            else:
+                lx = node[0][k, :, b] * (X[k, :, b] - node[1][k, :, b]) + node[2][k, :, b]
+            lam = lx + A[k, :, :, b].T @ lam
+    return Lam
+
+
+def backward(c, X, U, A, Bm, node=None, Hz=None):
+    """A (H,13,13,B), Bm (H,13,7,B) -> K (H,7,13,B), kff (H,7,B), dV (2,B).  Hz (H,21,21,B): optional second-order
+    dynamics blocks added to Qxx (rows/cols 0-12), Qux (rows 13-19, cols 0-12) and Quu (13-19, 13-19)."""
     H, _, B = U.shape
     q, qf, r = np.asarray(c.q, float), np.asarray(c.qf, float), np.asarray(c.r, float)
     K = np.zeros((H, 7, 13, B)); kff = np.zeros((H, 7, B)); dV = np.zeros((2, B))
@@ -40,6 +63,8 @@ def backward(c, X, U, A, Bm, node=None):
             Qxx = np.diag(q) + Ak.T @ Vxx @ Ak
             Qux = Bk.T @ Vxx @ Ak
             Quu = np.diag(r + c.reg) + Bk.T @ Vxx @ Bk
+            if Hz is not None:
+                Qxx = Qxx + Hz[k, :13, :13, b]; Qux = Qux + Hz[k, 13:20, :13, b]; Quu = Quu + Hz[k, 13:20, 13:20, b]
             Quu = 0.5 * (Quu + Quu.T)
             Kk = -np.linalg.solve(Quu, Qux); kk = -np.linalg.solve(Quu, Qu)
             K[k, :, :, b] = Kk; kff[k, :, b] = kk
