@@ -66,7 +66,7 @@ class ILQR(MultipleShooting):
     def __init__(self, *, system, dt: float = 0.01, num_nodes: int, cost: QuadraticCost, opts: Optional[dict] = None,
                  alphas: Sequence[float] = (1.0, 0.5, 0.25, 0.1, 0.03), hessian: str = "gauss-newton"):
         """hessian: 'gauss-newton' (first-order dynamics in the backward pass: iLQR) or 'exact' (adds the second-order
-        terms  sum_i lambda_i d2F_i/dz dz  of every node — what IPOPT gets from `nlp_hess_l`; analytic force models)."""
+        terms  sum_i lambda_i d2F_i/dz dz  of every node — what IPOPT gets from `nlp_hess_l`)."""
         super().__init__(system=system, dt=dt, num_nodes=num_nodes, opts=opts or {"quaternion": "integration"})
         assert 1 <= len(alphas) <= 8 and hessian in ("gauss-newton", "exact")
         self.cost = cost

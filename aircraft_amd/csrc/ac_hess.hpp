@@ -109,6 +109,65 @@ template <int N> AC_DI Jet2<N> m_atan2(const Jet2<N>& y, const Jet2<N>& x) {
     return r;
 }
 
+// ---- coefficient providers of the Hessian kernel ------------------------------------------------------------------
+template <int MODEL> struct HessAnalyticCoeffs : AnalyticCoeffs<MODEL> {
+    AC_DI HessAnalyticCoeffs(const float*, const UnitAddr&) {}
+    AC_DI void set_stage(int) {}
+};
+
+// MLP surrogate: chain rule through (y, J, T) of the stage, stored by k_nn_stage_tensors (ac_hess_nn.hpp) as
+// [4][126] floats per unit: y[6], J[6][5], T[6][15] (symmetric pairs p <= q).
+struct HessTensorCoeffs {
+    static constexpr int kModel = AC_MODEL_NN;
+    const float* __restrict__ base;
+    long blk;
+    int stage;
+    AC_DI HessTensorCoeffs(const float* tensors, const UnitAddr& ua) : base(tensors + ua.off(4 * 126)), blk(ua.blk), stage(0) {}
+    AC_DI void set_stage(int s) { stage = s; }
+    template <int N>
+    AC_DI void operator()(const DevParams& P, const AeroPre<Jet2<N>>& a, const Jet2<N>*, const Jet2<N> u[7],
+                          Jet2<N> C[6]) const {
+        const float* t = base + (long)stage * 126 * blk;
+        const Jet2<N> in[5] = {a.qbar, a.alpha, a.beta, u[0], u[1]};
+        Jet2<N> z[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) z[j] = (in[j] - P.mlp_in_mean[j]) * (1.0f / P.mlp_in_std[j]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float os = P.mlp_out_std[k];
+            Jet2<N> r(fmaf(t[(long)k * blk], os, P.mlp_out_mean[k]));
+            float ta[5];  // (T z.a)_q = sum_p T[p][q] z_p.a
+#pragma unroll
+            for (int q = 0; q < 5; ++q) ta[q] = 0.f;
+#pragma unroll
+            for (int p = 0; p < 5; ++p)
+#pragma unroll
+                for (int q = p; q < 5; ++q) {
+                    const float tpq = t[(long)(36 + k * 15 + (p * 5 - p * (p - 1) / 2 + (q - p))) * blk];
+                    ta[q] = fmaf(tpq, z[p].a, ta[q]);
+                    if (q != p) ta[p] = fmaf(tpq, z[q].a, ta[p]);
+                }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float Jkj = t[(long)(6 + k * 5 + j) * blk];
+                r.a = fmaf(Jkj, z[j].a, r.a);
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    r.d[i] = fmaf(Jkj, z[j].d[i], r.d[i]);
+                    r.h[i] = fmaf(Jkj, z[j].h[i], fmaf(ta[j], z[j].d[i], r.h[i]));
+                }
+            }
+            r.a *= os;
+#pragma unroll
+            for (int i = 0; i < N; ++i) { r.d[i] *= os; r.h[i] *= os; }
+            C[k] = r;
+        }
+        C[5] = C[5] + (-0.1f * 6.0f * kDeg) * u[2];
+    }
+};
+template <int MODEL> struct HessProvider { typedef HessAnalyticCoeffs<MODEL> type; };
+template <> struct HessProvider<AC_MODEL_NN> { typedef HessTensorCoeffs type; };
+
 // direction -> row/column of the 21 x 21 matrix over z = (x[13], u[7], dt); -1 = no such row
 template <bool QUAD> AC_DI int hess_index(int dir) {
     if (dir < 10) return 3 + dir;
@@ -131,7 +190,8 @@ template <int MODEL, int N>
 __global__ __launch_bounds__(kBlock) void k_step_hess(const DevParams P, const float* __restrict__ X,
                                                       const float* __restrict__ U, float dt,
                                                       const float* __restrict__ dt_per_unit,
-                                                      const float* __restrict__ Lam, long n, long blk,
+                                                      const float* __restrict__ Lam,
+                                                      const float* __restrict__ stage_tensors, long n, long blk,
                                                       float* __restrict__ Hout) {
     constexpr bool QUAD = MODEL == AC_MODEL_QUAD;
     constexpr int G = 16 / N;        // inner groups
@@ -153,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void k_step_hess(const DevParams P, const f
     // The seeds are 0/1 patterns of (a, g): they are rebuilt where they are used instead of being carried through the
     // RK4 loop (13 + 7 jets of registers otherwise), with the lane ids hidden from loop-invariant hoisting.
     auto seed_x = [&](int aa, int gg, int i) { return hess_seed<N, QUAD>(aa, gg, i >= 3 ? i - 3 : -1, xv[i]); };
-    AnalyticCoeffs<MODEL> coeffs;
+    typename HessProvider<MODEL>::type coeffs(stage_tensors, ua);
     T acc[13], xs[13], k[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) { xs[i] = seed_x(a, g, i); acc[i] = T(0.f); }
@@ -168,6 +228,7 @@ __global__ __launch_bounds__(kBlock) void k_step_hess(const DevParams P, const f
                 const int dir = QUAD ? (i < 4 ? 10 + i : -1) : ((i < 3) ? 10 + i : (i == 6 ? 13 : -1));
                 u[i] = hess_seed<N, QUAD>(aa, gg, dir, uv[i]);
             }
+            coeffs.set_stage(s);
             state_derivative(P, coeffs, xs, u, k);
         }
         const float wsum = (s == 1 || s == 2) ? 2.0f : 1.0f;

@@ -83,10 +83,16 @@ AC_DI void lds_dma_copy(const float* __restrict__ gsrc, char* lds_dst, int bytes
 // NSLAB slabs of 16 columns each.  TANGENT: slab 0 carries values and slabs 1..5 the five input tangents of the SAME
 // 16 units (NSLAB = 6).  Otherwise every slab is a value slab: NSLAB = 1 (16 units, the four lanes of a unit redundant)
 // or NSLAB = 4 (64 units, lane = unit; slab s = units 16 s .. 16 s + 15).  WT: register tiles per slab = width / 16.
-template <int NSLAB, int WT, bool USE_MFMA, bool TANGENT = (NSLAB == 6)>
+// SECOND (second-order mode, NSLAB == 6): slabs = value, d/dz_p, d/dz_q, d2/dz_p2, d2/dz_q2, d2/dz_p dz_q for one
+// input pair (p, q) set with set_pair(); used by the Hessian path (ac_hess_nn.hpp), never by the step kernels.
+template <int NSLAB, int WT, bool USE_MFMA, bool TANGENT = (NSLAB == 6), bool SECOND = false>
 struct MlpEngine {
     static_assert(!TANGENT || NSLAB == 6, "tangent mode = value + 5 input tangents");
+    static_assert(!SECOND || (NSLAB == 6 && !TANGENT), "second-order mode = value + 2 first-order + 3 second-order slabs");
     static constexpr bool kTangent = TANGENT;
+    static constexpr bool kDeriv = TANGENT || SECOND;  // slabs > 0 are derivative slabs (no bias, chain-rule epilogue)
+    int pair_p = 0, pair_q = 1;
+    AC_DI void set_pair(int p, int q) { pair_p = p; pair_q = q; }
     static constexpr int CH = WT < 4 ? WT : 4;  // output tiles computed together (independent accumulators)
 
     float a[NSLAB][WT][4];
@@ -129,11 +135,17 @@ struct MlpEngine {
     AC_DI void epilogue_tile(int s, int nt, const f32x4 (&o)[NT], int act) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (s == 0 || !TANGENT) {
+            if (s == 0 || !kDeriv) {
                 a[s][nt][r] = act ? act_tanh(o[nt][r]) : o[nt][r];
-            } else {
+            } else if (!SECOND || s <= 2) {
                 const float h = a[0][nt][r];  // already the NEW value activation
                 a[s][nt][r] = act ? o[nt][r] * fmaf(-h, h, 1.0f) : o[nt][r];
+            } else {
+                // h_ab = s'(z) z_ab + s''(z) z_a z_b with s'' = -2 h s' and z_a = h_a / s'  (h_a, h_b already NEW)
+                const float h = a[0][nt][r], sp = fmaf(-h, h, 1.0f);
+                const float ha = a[s == 4 ? 2 : 1][nt][r], hb = a[s == 3 ? 1 : 2][nt][r];
+                const float inv = sp > 1e-30f ? 1.0f / sp : 0.f;  // saturated neuron: both terms vanish
+                a[s][nt][r] = act ? fmaf(o[nt][r], sp, -2.0f * h * ha * hb * inv) : o[nt][r];
             }
         }
     }
@@ -153,7 +165,7 @@ struct MlpEngine {
         f32x4 acc[CNT];
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
-            if (s == 0 || !TANGENT) acc[i] = bias4[(nc + i) * 4 + g];  // a value slab starts from the bias
+            if (s == 0 || !kDeriv) acc[i] = bias4[(nc + i) * 4 + g];  // a value slab starts from the bias
             else acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         f32x4 wnext[CNT];
@@ -231,7 +243,7 @@ struct MlpEngine {
         const f32x4* bias4 = reinterpret_cast<const f32x4*>(wl + WT * 1024);
         const f32x4* w0t = reinterpret_cast<const f32x4*>(wl + WT * 1024 + 1024);  // [5][16*WT] floats
 #pragma unroll
-        for (int sv = 0; sv < (TANGENT ? 1 : NSLAB); ++sv) {  // every value slab
+        for (int sv = 0; sv < (kDeriv ? 1 : NSLAB); ++sv) {  // every value slab
             f32x4 o[WT];
 #pragma unroll
             for (int nt = 0; nt < WT; ++nt) {
@@ -257,6 +269,24 @@ struct MlpEngine {
                     }
                 }
         }
+        if constexpr (SECOND) {
+            // z = W0 in + b is linear in the inputs: h_a = s' W0[:, a], h_ab = s'' W0[:, a] W0[:, b] = -2 h h_a W0[:, b]
+#pragma unroll
+            for (int nt = 0; nt < WT; ++nt) {
+                const f32x4 wp = w0t[pair_p * (WT * 4) + 4 * nt + g];
+                const f32x4 wq = w0t[pair_q * (WT * 4) + 4 * nt + g];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float h = a[0][nt][r], sp = fmaf(-h, h, 1.0f);
+                    const float hp = act ? wp[r] * sp : wp[r], hq = act ? wq[r] * sp : wq[r];
+                    a[1][nt][r] = hp;
+                    a[2][nt][r] = hq;
+                    a[3][nt][r] = act ? -2.0f * h * hp * wp[r] : 0.f;
+                    a[4][nt][r] = act ? -2.0f * h * hq * wq[r] : 0.f;
+                    a[5][nt][r] = act ? -2.0f * h * hp * wq[r] : 0.f;
+                }
+            }
+        }
     }
 
     // LDS address of layer l's block; for a streamed layer: wait for its DMA, then (the barrier having
@@ -278,7 +308,7 @@ struct MlpEngine {
     // when layers are streamed, workgroup-collective (one barrier per streamed layer).
     AC_DI void forward(const float z[5], float y[6], float (*J)[5]) {
         const int col = lane & 15;
-        if constexpr (!TANGENT && NSLAB > 1) {
+        if constexpr (!kDeriv && NSLAB > 1) {
             // multi-value mode: lane = unit.  Slab s needs z of unit 16 s + col in rows 0..4 (row k on lane group k>>2).
 #pragma unroll
             for (int sl = 0; sl < NSLAB; ++sl) {
@@ -303,6 +333,11 @@ struct MlpEngine {
 #pragma unroll
                     for (int j = 0; j < 5; ++j) a[1 + j][0][r] = (row == j) ? 1.f : 0.f;
                 }
+                if constexpr (SECOND) {
+                    a[1][0][r] = (row == pair_p) ? 1.f : 0.f;
+                    a[2][0][r] = (row == pair_q) ? 1.f : 0.f;
+                    a[3][0][r] = 0.f; a[4][0][r] = 0.f; a[5][0][r] = 0.f;
+                }
             }
         }
         const int L = plan.n_layers;
@@ -323,7 +358,7 @@ struct MlpEngine {
             AC_MARK(st, 5);  // [5] last layer
         }
         // outputs: rows 0..5 of tile 0 — row k sits in register k&3 of lane (col, k>>2)
-        if constexpr (!TANGENT && NSLAB > 1) {
+        if constexpr (!kDeriv && NSLAB > 1) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 float v = 0.f;
@@ -339,7 +374,7 @@ struct MlpEngine {
             for (int k = 0; k < 6; ++k) {
                 const int src = col + 16 * (k >> 2);
                 y[k] = __shfl(a[0][0][k & 3], src, 64);
-                if constexpr (kTangent) {
+                if constexpr (kDeriv) {  // SECOND: J[k][0..4] = dy/dz_p, dy/dz_q, d2y/dz_p2, d2y/dz_q2, d2y/dz_p dz_q
 #pragma unroll
                     for (int j = 0; j < 5; ++j) J[k][j] = __shfl(a[1 + j][0][k & 3], src, 64);
                 }

@@ -13,6 +13,7 @@
 #include "ac_ilqr.hpp"
 #include "ac_track.hpp"
 #include "ac_hess.hpp"
+#include "ac_hess_nn.hpp"
 
 using namespace ac;
 
@@ -62,6 +63,8 @@ struct ac_handle {
     int use_mfma;
     float* d_blob;  // packed MLP weights + biases (device)
     size_t blob_floats;
+    float* d_hess_ws;  // [n][4][126] stage tensors of the MLP Hessian path, grown on demand
+    size_t hess_ws_floats;
     float* d_track;  // [nseg][3][4] segment cubics (device)
     TrackDev track;
     // last launch (profiling aid)
@@ -112,7 +115,8 @@ void launch_hess(ac_handle* h, hipStream_t st, const float* X, const float* U, f
     constexpr int N = HessN<MODEL>::value;
     constexpr int upb = kBlock / (16 * (16 / N));  // units per workgroup
     const int grid = (int)((n + upb - 1) / upb);
-    hipLaunchKernelGGL((k_step_hess<MODEL, N>), grid, kBlock, 0, st, h->dp, X, U, dt, dt_per_unit, Lam, n, blk, Hout);
+    hipLaunchKernelGGL((k_step_hess<MODEL, N>), grid, kBlock, 0, st, h->dp, X, U, dt, dt_per_unit, Lam,
+                       (const float*)h->d_hess_ws, n, blk, Hout);
     *grid_out = grid;
 }
 
@@ -176,6 +180,7 @@ int ac_destroy(ac_handle* h) {
     if (!h) return AC_ERR_BAD_ARG;
     if (h->d_blob) (void)hipFree(h->d_blob);
     if (h->d_track) (void)hipFree(h->d_track);
+    if (h->d_hess_ws) (void)hipFree(h->d_hess_ws);
     delete h;
     return AC_OK;
 }
@@ -518,12 +523,40 @@ static int hess_impl(ac_handle* h, const float* X, const float* U, float dt, con
                      long n, long blk, float* Hout, void* stream) {
     if (h && n == 0) return AC_OK;
     if (!h || !X || !U || !Lam || !Hout || n < 0 || blk <= 0) return AC_ERR_BAD_ARG;
-    if (h->dp.p.model_kind == AC_MODEL_NN || h->dp.p.substeps != 1) return AC_ERR_UNSUPPORTED;
+    if (h->dp.p.substeps != 1) return AC_ERR_UNSUPPORTED;
     int rc = model_ready(h);
     if (rc != AC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     AC_HIP(hipMemsetAsync(Hout, 0, (size_t)n * 441 * sizeof(float), st));
     int grid = 0;
+    if (h->dp.p.model_kind == AC_MODEL_NN) {
+        // stage tensors (y, J, T at the four RK4 stage points) into the handle's workspace, then the same second-order
+        // kernel with the tensor provider.  The workspace grows on demand: the first call of a given size allocates.
+        const size_t need = (size_t)n * kStageFloats;
+        if (need > h->hess_ws_floats) {
+            AC_HIP(hipStreamSynchronize(st));
+            if (h->d_hess_ws) (void)hipFree(h->d_hess_ws);
+            h->d_hess_ws = nullptr; h->hess_ws_floats = 0;
+            AC_HIP(hipMalloc((void**)&h->d_hess_ws, need * sizeof(float)));
+            h->hess_ws_floats = need;
+        }
+        const int grid_t = (int)((n + 63) / 64);
+        const int lds = h->plan.lds_total;
+        bool launched = false;
+        AC_NN_CASE(2, true, (k_nn_stage_tensors<2, true>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
+        AC_NN_CASE(4, true, (k_nn_stage_tensors<4, true>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
+        AC_NN_CASE(8, true, (k_nn_stage_tensors<8, true>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
+        AC_NN_CASE(2, false, (k_nn_stage_tensors<2, false>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
+        AC_NN_CASE(4, false, (k_nn_stage_tensors<4, false>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
+        AC_NN_CASE(8, false, (k_nn_stage_tensors<8, false>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
+        if (!launched) return AC_ERR_UNSUPPORTED;
+        (void)lds;
+        AC_HIP(hipGetLastError());
+        launch_hess<AC_MODEL_NN>(h, st, X, U, dt, dt_per_unit, Lam, n, blk, Hout, &grid);
+        note_launch(h, "k_step_hess", grid, kBlock, 0);
+        AC_HIP(hipGetLastError());
+        return AC_OK;
+    }
     switch (h->dp.p.model_kind) {
         case AC_MODEL_LINEAR: launch_hess<AC_MODEL_LINEAR>(h, st, X, U, dt, dt_per_unit, Lam, n, blk, Hout, &grid); break;
         case AC_MODEL_POLY: launch_hess<AC_MODEL_POLY>(h, st, X, U, dt, dt_per_unit, Lam, n, blk, Hout, &grid); break;

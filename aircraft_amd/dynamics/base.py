@@ -286,7 +286,7 @@ class SixDOF(ABC):
     def step_hess(self, x, u, dt, lam, out=None):
         """Hessian of lam . F(x, u, dt) over z = (x[13], u[7], dt): (21, 21, n) — the block the defect rows contribute to
         the Lagrangian Hessian IPOPT evaluates as `nlp_hess_l` (control/base.py:279-280; todo.md:102).
-        lam (13, n): multipliers of the rows of F.  Analytic force models and one RK4 sub-step only."""
+        lam (13, n): multipliers of the rows of F.  One RK4 sub-step only."""
         lib = self._sync()
         torch = _torch()
         X, npx, vec = self._in(x, self.num_states, "x")

@@ -45,6 +45,27 @@ def test_hessian_matches_finite_differences_of_exact_jacobians(gpu, model, norma
     assert np.abs(want[[0, 1, 2, 16, 17, 18]]).max() < 1e-6 * np.abs(want).max()
 
 
+@pytest.mark.parametrize("hidden,normalise,use_mfma", [((64, 64, 64), True, True), (None, False, True), ((128, 128, 128, 128), True, True),
+                                                       ((32, 32), True, False)])
+def test_hessian_mlp_surrogate(gpu, hidden, normalise, use_mfma):
+    """MLP surrogate: stage tensors (y, J, d2y/dz dz) from the MFMA engine's second-order mode, then the same
+    second-order forward-mode kernel.  hidden=None is the reference's own network (Linear-tanh-Linear)."""
+    ac = make_aircraft("nn", hidden=hidden, normalise=normalise, use_mfma=use_mfma)
+    orc = make_oracle(ac)
+    X, U, lam = units(80, seed=41)
+    Hm = ac.step_hess(dev(X, gpu), dev(U, gpu), 0.01, dev(lam, gpu)).cpu().numpy().astype(np.float64)
+    want = oracle_step_hessian(orc, X, U, 0.01, lam)
+    assert np.isfinite(Hm).all()
+    assert rel_block(Hm, want) < 5e-4
+    assert np.abs(Hm - Hm.transpose(1, 0, 2)).max() <= 2e-5 * np.abs(Hm).max()
+    for z in (0, 1, 2, 16, 17, 18):
+        assert not Hm[z].any() and not Hm[:, z].any()
+    # a second, larger call re-uses / grows the handle's workspace
+    X2, U2, lam2 = units(300, seed=42)
+    H2 = ac.step_hess(dev(X2, gpu), dev(U2, gpu), 0.01, dev(lam2, gpu)).cpu().numpy().astype(np.float64)
+    assert rel_block(H2[:, :, :40], oracle_step_hessian(orc, X2[:, :40], U2[:, :40], 0.01, lam2[:, :40])) < 5e-4
+
+
 def test_hessian_per_unit_dt_and_numpy_vector(gpu):
     ac = make_aircraft("poly", normalise=True)
     orc = make_oracle(ac)
@@ -100,9 +121,6 @@ def test_hessian_unsupported_cases_fail_loudly(gpu):
     from aircraft_amd import AircraftHipError
 
     X, U, lam = units(8, seed=1)
-    nn = make_aircraft("nn", hidden=(32, 32))
-    with pytest.raises(AircraftHipError, match="UNSUPPORTED"):
-        nn.step_hess(dev(X, gpu), dev(U, gpu), 0.01, dev(lam, gpu))
     ac = make_aircraft("poly")
     ac.physical_integration_substeps = 2
     with pytest.raises(AircraftHipError, match="UNSUPPORTED"):

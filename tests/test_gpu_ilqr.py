@@ -169,6 +169,9 @@ def test_exact_hessian_solve_reaches_the_same_minimum(gpu):
     # the path, not the destination)
     assert (np.abs(h_nt[-1] - h_gn[-1]) <= 0.02 * np.abs(h_gn[-1]) + 1e-3).mean() > 0.9
     assert block_rel_err(Xn.cpu().numpy(), newton.rollout(dev(X0, gpu), Un).cpu().numpy()) < 5e-5
-    with pytest.raises(Exception, match="UNSUPPORTED"):  # the MLP surrogate has no second-order kernel
-        acn, iln, costn, X0n, Un_ = setup(gpu, "nn", (32, 32), B=8, H=6)
-        ILQR(system=acn, dt=0.01, num_nodes=6, cost=costn, hessian="exact").solve(dev(X0n, gpu), dev(Un_, gpu), iters=1)
+    # the MLP surrogate takes the same path (stage tensors from the MFMA engine's second-order mode)
+    acn, iln, costn, X0n, Un_ = setup(gpu, "nn", (32, 32), B=16, H=10)
+    nn_newton = ILQR(system=acn, dt=0.01, num_nodes=10, cost=costn, alphas=(1.0, 0.5, 0.1), hessian="exact")
+    _, _, hn = nn_newton.solve(dev(X0n, gpu), dev(np.zeros_like(Un_), gpu), iters=3)
+    hn = hn.cpu().numpy()
+    assert np.isfinite(hn).all() and (np.diff(hn, axis=0) <= 1e-6 * np.abs(hn[:-1]) + 1e-6).all()

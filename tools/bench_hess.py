@@ -17,9 +17,14 @@ U = torch.from_numpy(np.ascontiguousarray(synthetic_controls(H, B, rng), dtype=n
 Lam = torch.randn(H, 13, B, device=dev)
 out = torch.empty(H, 21, 21, B, device=dev)
 res = {}
-for model in ("default", "linear", "poly", "quad"):
+from aircraft_amd import MlpData
+for model in ("default", "linear", "poly", "quad", "nn3x64", "nn4x128"):
     if model == "quad":
         ac = Quadrotor()
+    elif model.startswith("nn"):
+        hidden = (64, 64, 64) if model == "nn3x64" else (128, 128, 128, 128)
+        ac = Aircraft(AircraftOpts(coeff_model_type="nn", coeff_model_path=MlpData.synthetic(hidden, seed=42),
+                                   aircraft_config=AircraftConfiguration(dict(GLIDER)), physical_integration_substeps=1))
     else:
         path = {"poly": os.path.join(ROOT, "tests/golden/poly_coef.npz"), "linear": os.path.join(ROOT, "tests/golden/linearised.npz")}.get(model, "")
         if model == "linear":
