@@ -104,3 +104,53 @@ def test_single_layer_and_odd_width_networks(gpu):
         Ur = np.repeat(U[None], 6, axis=0)
         roll = ac.rollout(Xd, torch.from_numpy(Ur).float().to(gpu), 0.01).cpu().numpy()
         assert block_rel_err(roll[1], Xr) < 1e-5
+
+
+def test_status_codes_of_the_widened_entry_points(gpu):
+    """Track / MHTT / Hessian / Newton entry points: empty batches, NULL arguments, missing track, bad modes."""
+    import torch
+
+    from aircraft_amd import _lib
+
+    lib = _lib.load()
+    ac = make_aircraft("poly")
+    ac._sync()
+    h = ac._handle
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    f = lambda *s: torch.zeros(s, device=gpu)  # noqa: E731
+    B, H = 8, 3
+    X, U, Lam, Hz = f(H + 1, 13, B), f(H, 7, B), f(H, 13, B), f(H, 21, 21, B)
+    S, s0, J = f(H + 1, B), f(B), f(B)
+    w = _lib.MhttWeights(10, 5, 2, 50, 20, 10, 100)
+    cost = _lib.IlqrCost()
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    nul = C.c_void_p(0)
+    # no track installed yet
+    assert lib.ac_track_progress_f32(h, C.byref(w), p(X), p(s0), C.c_float(0.01), B, H, 1, p(S), nul, nul, nul, nul, nul, st) == -4
+    assert lib.ac_mhtt_loss_f32(h, C.byref(w), p(X), p(U), p(S), B, H, p(J), st) == -4
+    assert lib.ac_track_eval_f32(h, p(s0), B, p(f(3, B)), p(f(3, B)), st) == -4
+    fp = C.POINTER(C.c_float)
+    coef = np.zeros((2, 3, 4), dtype=np.float32); coef[:, 0, 1] = 1.0
+    assert lib.ac_set_track(h, 2, coef.ctypes.data_as(fp), C.c_float(0.0)) == -1      # length must be positive
+    assert lib.ac_set_track(h, 0, coef.ctypes.data_as(fp), C.c_float(2.0)) == -1
+    assert lib.ac_set_track(h, 2, coef.ctypes.data_as(fp), C.c_float(2.0)) == 0
+    assert lib.ac_track_progress_f32(h, C.byref(w), p(X), p(s0), C.c_float(0.01), B, H, 1, p(S), nul, nul, nul, nul, nul, st) == 0
+    assert lib.ac_track_progress_f32(h, C.byref(w), p(X), p(s0), C.c_float(0.01), B, H, 2, p(S), nul, nul, nul, nul, nul, st) == -1  # mode
+    assert lib.ac_track_progress_f32(h, C.byref(w), p(X), p(s0), C.c_float(0.01), B, H, 1, p(S), nul, nul, p(X), nul, nul, st) == -1  # model arrays: all three or none
+    assert lib.ac_track_progress_f32(h, None, nul, nul, C.c_float(0.01), 0, H, 1, nul, nul, nul, nul, nul, nul, st) == 0  # empty batch
+    assert lib.ac_mhtt_loss_f32(h, C.byref(w), p(X), p(U), p(S), B, H, p(J), st) == 0
+    assert lib.ac_mhtt_loss_f32(h, None, p(X), p(U), p(S), B, H, p(J), st) == -1
+    # Hessians
+    assert lib.ac_shoot_hess_f32(h, p(X), p(U), C.c_float(0.01), nul, p(Lam), B, H, p(Hz), st) == 0
+    assert lib.ac_shoot_hess_f32(h, p(X), p(U), C.c_float(0.01), nul, nul, B, H, p(Hz), st) == -1
+    assert lib.ac_shoot_hess_f32(h, nul, nul, C.c_float(0.01), nul, nul, 0, H, nul, st) == 0
+    assert lib.ac_step_hess_f32(h, p(X), p(U), C.c_float(0.01), nul, p(Lam), -1, p(Hz), st) == -1
+    # Newton sweep pieces
+    A, Bm = f(H, 13, 13, B), f(H, 13, 7, B)
+    K, kff, dV = f(H, 7, 13, B), f(H, 7, B), f(2, B)
+    assert lib.ac_ilqr_costate_f32(h, C.byref(cost), nul, nul, nul, p(X), p(A), B, H, p(Lam), st) == 0
+    assert lib.ac_ilqr_costate_f32(h, C.byref(cost), p(X), nul, nul, p(X), p(A), B, H, p(Lam), st) == -1
+    assert lib.ac_ilqr_backward_newton_f32(h, C.byref(cost), nul, nul, nul, p(Hz), p(X), p(U), p(A), p(Bm), B, H, p(K), p(kff), p(dV), st) == 0
+    assert lib.ac_ilqr_backward_newton_f32(h, C.byref(cost), nul, nul, nul, p(Hz), p(X), p(U), p(A), p(Bm), B, 0, p(K), p(kff), p(dV), st) == -1
+    assert lib.ac_ilqr_cost_node_f32(h, C.byref(cost), p(X), p(X), p(X), 0, p(X), p(U), B, H, p(J), st) == -1  # Bn must be > 0
+    torch.cuda.synchronize()
