@@ -33,9 +33,11 @@ struct NodeCost {
     long Bn;
     AC_DI bool on() const { return q != nullptr; }
     // value and gradient pieces of row j at node k
-    AC_DI void row(const IlqrCost& C, long k, bool terminal, int j, long b, float& qj, float& xr, float& gl) const {
-        if (on()) {
-            const long o = (k * 13 + j) * Bn + (b % Bn);
+    // NODE is a compile-time switch of the kernels (constant cost = the original straight-line code); bn = b % Bn
+    template <bool NODE>
+    AC_DI void row(const IlqrCost& C, long k, bool terminal, int j, long bn, float& qj, float& xr, float& gl) const {
+        if constexpr (NODE) {
+            const long o = (k * 13 + j) * Bn + bn;
             qj = q[o]; xr = xref[o]; gl = glin[o];
         } else {
             qj = terminal ? C.qf[j] : C.q[j];
@@ -56,7 +58,7 @@ struct AlphaSet {
 // next to the linearisation that feeds it, so it is written for clarity, not for the roofline.
 constexpr int kIlqrFloats = 1024;  // LDS floats per instance (layout below)
 
-template <int kUnused = 0>  // template: this header is included by several translation units
+template <bool NODE, bool NEWTON>  // per-node cost arrays or the constant cost; second-order dynamics blocks or none
 __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const NodeCost N, const float* __restrict__ X,
                                                       const float* __restrict__ U, const float* __restrict__ A,
                                                       const float* __restrict__ Bm, const float* __restrict__ Hz, long B, long H,
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const No
     if (j < 13) {
         const float xn = X[(H * 13 + j) * B + b];
         float qj, xr, gl;
-        N.row(C, H, true, j, b, qj, xr, gl);
+        N.template row<NODE>(C, H, true, j, b, qj, xr, gl);
         svx[j] = fmaf(qj, xn - xr, gl);
         for (int i = 0; i < 13; ++i) sV[i * 13 + j] = (i == j) ? qj : 0.f;
     }
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const No
             for (int i = 0; i < 13; ++i) sA[i * 13 + j] = A[((k * 13 + i) * 13 + j) * B + b];
             const float xk = X[(k * 13 + j) * B + b];
             float xr, gl;
-            N.row(C, k, false, j, b, qjj, xr, gl);
+            N.template row<NODE>(C, k, false, j, b, qjj, xr, gl);
             sqx[j] = fmaf(qjj, xk - xr, gl);
         }
         if (j < 7) {
@@ -132,15 +134,15 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const No
             qx = sqx[j];
             for (int m = 0; m < 13; ++m) qx = fmaf(sA[m * 13 + j], svx[m], qx);
             // Hz (optional): second-order dynamics terms  sum_i lambda_i d2F_i/dz dz  of this node, z = (x, u, dt)
-            const float* hz = Hz ? Hz + (k * 441) * B + b : nullptr;
+            const float* hz = NEWTON ? Hz + (k * 441) * B + b : nullptr;
             for (int i = 0; i < 13; ++i) {
                 float s = (i == j) ? qjj : 0.f;
-                if (hz) s += hz[((long)i * 21 + j) * B];
+                if constexpr (NEWTON) s += hz[((long)i * 21 + j) * B];
                 for (int m = 0; m < 13; ++m) s = fmaf(sA[m * 13 + i], sVA[m * 13 + j], s);
                 qxx[i] = s;
             }
             for (int i = 0; i < 7; ++i) {
-                float s = hz ? hz[((long)(13 + i) * 21 + j) * B] : 0.f;
+                float s = NEWTON ? hz[((long)(13 + i) * 21 + j) * B] : 0.f;
                 for (int m = 0; m < 13; ++m) s = fmaf(sB[m * 7 + i], sVA[m * 13 + j], s);
                 sQux[i * 13 + j] = s;
             }
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const No
             squ[j] = qu;  // now holds Qu
             for (int i = 0; i < 7; ++i) {
                 float s = (i == j) ? C.r[j] + C.reg : 0.f;
-                if (Hz) s += Hz[((k * 21 + 13 + i) * 21 + 13 + j) * B + b];
+                if constexpr (NEWTON) s += Hz[((k * 21 + 13 + i) * 21 + 13 + j) * B + b];
                 for (int m = 0; m < 13; ++m) s = fmaf(sB[m * 7 + i], sVB[m * 7 + j], s);
                 sQuu[i * 7 + j] = s;
             }
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const No
 // Multipliers of the defect rows x_{k+1} = F(x_k, u_k) at the current iterate (the NLP's lambda estimate):
 //   Lam[H-1] = grad l_N(x_N),   Lam[k-1] = grad l_k(x_k) + A_k' Lam[k]
 // One lane per instance, sequential in k; feeds ac_shoot_hess_f32 for the exact-Hessian (Newton) backward pass.
-template <int kUnused = 0>
+template <bool NODE>
 __global__ __launch_bounds__(kBlock) void k_ilqr_costate(const IlqrCost C, const NodeCost N, const float* __restrict__ X,
                                                          const float* __restrict__ A, long B, long H,
                                                          float* __restrict__ Lam) {
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_ilqr_costate(const IlqrCost C, const
 #pragma unroll
     for (int j = 0; j < 13; ++j) {
         float qj, xr, gl;
-        N.row(C, H, true, j, b, qj, xr, gl);
+        N.template row<NODE>(C, H, true, j, b, qj, xr, gl);
         lam[j] = fmaf(qj, X[(H * 13 + j) * B + b] - xr, gl);
     }
     for (long k = H - 1;; --k) {
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void k_ilqr_costate(const IlqrCost C, const
 #pragma unroll
         for (int j = 0; j < 13; ++j) {
             float qj, xr, gl;
-            N.row(C, k, false, j, b, qj, xr, gl);
+            N.template row<NODE>(C, k, false, j, b, qj, xr, gl);
             float s = fmaf(qj, X[(k * 13 + j) * B + b] - xr, gl);
 #pragma unroll
             for (int m = 0; m < 13; ++m) s = fmaf(A[((k * 13 + m) * 13 + j) * B + b], lam[m], s);
@@ -275,21 +277,22 @@ __global__ __launch_bounds__(kBlock) void k_ilqr_costate(const IlqrCost C, const
 }
 
 // ---- quadratic trajectory cost ---------------------------------------------------------------------
-template <int kUnused = 0>
+template <bool NODE>
 __global__ __launch_bounds__(kBlock) void k_ilqr_cost(const IlqrCost C, const NodeCost N, const float* __restrict__ X,
                                                       const float* __restrict__ U, long B, long H,
                                                       float* __restrict__ cost) {
     const long b = (long)blockIdx.x * kBlock + threadIdx.x;
     if (b >= B) return;
     float acc = 0.f;
+    const long bn = NODE ? b % N.Bn : b;
     for (long k = 0; k <= H; ++k) {
 #pragma unroll
         for (int i = 0; i < 13; ++i) {
             float qi, xr, gl;
-            N.row(C, k, k == H, i, b, qi, xr, gl);
+            N.template row<NODE>(C, k, k == H, i, bn, qi, xr, gl);
             const float x = X[(k * 13 + i) * B + b], d = x - xr;
             acc = fmaf(0.5f * qi * d, d, acc);
-            acc = fmaf(gl, x, acc);
+            if constexpr (NODE) acc = fmaf(gl, x, acc);
         }
         if (k < H) {
 #pragma unroll

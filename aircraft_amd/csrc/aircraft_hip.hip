@@ -618,7 +618,8 @@ int ac_ilqr_costate_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* nod
     if ((node_q || node_xref || node_glin) && !(node_q && node_xref && node_glin)) return AC_ERR_BAD_ARG;
     const NodeCost nc{node_q, node_xref, node_glin, B};
     const int grid = (int)((B + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_ilqr_costate<0>, grid, kBlock, 0, (hipStream_t)stream, to_dev_cost(cost), nc, X, A, B, H, Lam);
+    if (node_q) hipLaunchKernelGGL(k_ilqr_costate<true>, grid, kBlock, 0, (hipStream_t)stream, to_dev_cost(cost), nc, X, A, B, H, Lam);
+    else hipLaunchKernelGGL(k_ilqr_costate<false>, grid, kBlock, 0, (hipStream_t)stream, to_dev_cost(cost), nc, X, A, B, H, Lam);
     note_launch(h, "k_ilqr_costate", grid, kBlock, 0);
     AC_HIP(hipGetLastError());
     return AC_OK;
@@ -633,7 +634,13 @@ int ac_ilqr_backward_newton_f32(ac_handle* h, const ac_ilqr_cost* cost, const fl
     const NodeCost nc{node_q, node_xref, node_glin, B};
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)((B + 3) / 4);
-    hipLaunchKernelGGL(k_ilqr_backward<0>, grid, 64, 0, st, to_dev_cost(cost), nc, X, U, A, Bm, Hz, B, H, K, kff, dV);
+#define AC_BACKWARD(NODE_, NEWTON_) \
+    hipLaunchKernelGGL((k_ilqr_backward<NODE_, NEWTON_>), grid, 64, 0, st, to_dev_cost(cost), nc, X, U, A, Bm, Hz, B, H, K, kff, dV)
+    if (node_q && Hz) AC_BACKWARD(true, true);
+    else if (node_q) AC_BACKWARD(true, false);
+    else if (Hz) AC_BACKWARD(false, true);
+    else AC_BACKWARD(false, false);
+#undef AC_BACKWARD
     note_launch(h, "k_ilqr_backward", grid, 64, 4 * kIlqrFloats * 4);
     AC_HIP(hipGetLastError());
     return AC_OK;
@@ -653,7 +660,8 @@ int ac_ilqr_cost_node_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* n
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)((B + kBlock - 1) / kBlock);
     const NodeCost nc{node_q, node_xref, node_glin, Bn > 0 ? Bn : 1};
-    hipLaunchKernelGGL(k_ilqr_cost<0>, grid, kBlock, 0, st, to_dev_cost(cost), nc, X, U, B, H, out);
+    if (node_q) hipLaunchKernelGGL(k_ilqr_cost<true>, grid, kBlock, 0, st, to_dev_cost(cost), nc, X, U, B, H, out);
+    else hipLaunchKernelGGL(k_ilqr_cost<false>, grid, kBlock, 0, st, to_dev_cost(cost), nc, X, U, B, H, out);
     note_launch(h, "k_ilqr_cost", grid, kBlock, 0);
     AC_HIP(hipGetLastError());
     return AC_OK;
