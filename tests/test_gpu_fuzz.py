@@ -1,0 +1,59 @@
+"""Seeded differential sweep: random (model, sub-steps, normalise, stall scaling, dt, batch size) configurations, every
+entry point of the step path against the float64 oracle.  Catches interactions the targeted parity tests do not pair
+up (e.g. stall scaling x sub-stepped sensitivities x per-unit dt on a ragged batch)."""
+import numpy as np
+import pytest
+
+from tests.helpers import (block_rel_err, f32_exact, make_aircraft, make_oracle, oracle_step_hessian, rel_fro,
+                           synthetic_units)
+
+pytestmark = pytest.mark.gpu
+
+MODELS = [("default", None), ("linear", None), ("poly", None), ("nn", None), ("nn", (48, 40)), ("nn", (64, 64, 64))]
+
+
+def dev(a, gpu):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(gpu)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configuration(gpu, seed):
+    rng = np.random.default_rng(1000 + seed)
+    model, hidden = MODELS[seed % len(MODELS)]
+    substeps = int(rng.choice([1, 1, 2, 3]))
+    normalise = bool(rng.integers(2))
+    stall = bool(rng.integers(2))
+    n = int(rng.choice([1, 15, 17, 63, 65, 250, 1025]))
+    dt = float(rng.choice([0.005, 0.01, 0.02]))
+    ac = make_aircraft(model, hidden=hidden, substeps=substeps, normalise=normalise, stall_scaling=stall)
+    orc = make_oracle(ac)
+    X, U = synthetic_units(n, seed=seed, flaps=bool(rng.integers(2)))
+    tag = f"{model}{hidden} substeps={substeps} normalise={normalise} stall={stall} n={n} dt={dt}"
+    Xd, Ud = dev(X, gpu), dev(U, gpu)
+    # derivative and step
+    xd = ac.state_derivative(Xd, Ud).cpu().numpy()
+    want = orc.state_derivative(X, U)
+    assert np.abs(xd - want).max() / max(np.abs(want).max(), 1.0) < 5e-6, tag
+    per_unit = bool(rng.integers(2))
+    dts = f32_exact(rng.uniform(0.5 * dt, 1.5 * dt, n)) if per_unit else dt
+    xn = ac.state_update(Xd, Ud, dev(dts, gpu) if per_unit else dt).cpu().numpy()
+    assert block_rel_err(xn, orc.state_update(X, U, dts)) < 5e-6, tag
+    # sensitivities
+    Xn, A, Bm, c = ac.step_sens(Xd, Ud, dev(dts, gpu) if per_unit else dt)
+    Xr, Ar, Br, cr = orc.step_sens(X, U, dts)
+    assert block_rel_err(Xn.cpu().numpy(), Xr) < 5e-6, tag
+    assert rel_fro(A.cpu().numpy(), Ar) < 2e-5 and rel_fro(Bm.cpu().numpy(), Br) < 1e-4 and rel_fro(c.cpu().numpy(), cr) < 1e-4, tag
+    # second-order blocks (one RK4 sub-step only)
+    if substeps == 1 and n <= 250:
+        lam = f32_exact(rng.normal(size=(13, n)))
+        Hm = ac.step_hess(Xd, Ud, dev(dts, gpu) if per_unit else dt, dev(lam, gpu)).cpu().numpy().astype(np.float64)
+        Hr = oracle_step_hessian(orc, X, U, dts, lam)
+        num = np.sqrt(((Hm - Hr) ** 2).sum(axis=(0, 1))); den = np.sqrt((Hr ** 2).sum(axis=(0, 1)))
+        assert (num / np.maximum(den, 1e-30)).max() < 1e-3, tag
+    # a short rollout from the same states
+    H = 6
+    Uh = f32_exact(np.tile(U[None], (H, 1, 1)))
+    traj = ac.rollout(Xd, dev(Uh, gpu), dt).cpu().numpy()
+    assert block_rel_err(traj, orc.rollout(X, Uh, dt)) < 2e-5, tag
