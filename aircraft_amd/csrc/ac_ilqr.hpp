@@ -53,10 +53,30 @@ struct AlphaSet {
 };
 
 // ---- backward (Riccati) pass ------------------------------------------------------------------
-// 16 lanes per instance (lane j owns column j of the 13-wide matrices / column j of the 7-wide ones), 4 instances per
-// 64-thread workgroup, all matrices of an instance in LDS.  Sequential in k; negligible flops (~15 kflop per node)
-// next to the linearisation that feeds it, so it is written for clarity, not for the roofline.
-constexpr int kIlqrFloats = 1024;  // LDS floats per instance (layout below)
+// One wave per instance: lane (j, rb) = (t & 15, t >> 4) owns rows rb, rb+4, rb+8, (rb+12) of column j of the 13-wide
+// matrices (and of the 7-wide ones), all matrices of the instance in LDS.  The 7x7 Cholesky and the triangular solves
+// run redundantly in registers on every lane.  Sequential in k; ~15 kflop per node, so what matters is latency:
+//  * the inputs of a node (A_k, B_k, x_k, u_k, its cost rows, its second-order block) are 260-760 floats that sit
+//    B floats apart in HBM (the arrays are instance-minor for the kernels that produce them), i.e. one cache line and
+//    one page each — fetched on demand they cost ~10 us per node.  They are gathered by LDS-DMA (per-lane source
+//    address, lane-linear LDS image) into a ring kRing nodes deep, several nodes ahead of the one being processed,
+//    with a counted s_waitcnt vmcnt(N): nothing in the loop waits on an ordinary global load;
+//  * one wave = one workgroup, so LDS hand-offs need only lgkmcnt(0), never a cross-wave barrier.
+constexpr int kIlqrWork = 736;  // LDS floats of the per-instance work area (layout below)
+
+template <bool NODE, bool NEWTON> struct IlqrRing {
+    static constexpr int kInstr = 6 + (NEWTON ? 7 : 0);          // LDS-DMA wave-instructions per node
+    static constexpr int kNodeFloats = NEWTON ? 768 : 320;      // A 0..168, B 169..259, x 260, u 273, q 280, xref 293, glin 306, Hz 320..760
+    static constexpr int kDepth = NEWTON ? 5 : 8;                // nodes in flight (kInstr * (kDepth - 1) <= 63)
+    static_assert(kInstr * (kDepth - 1) <= 63, "vmcnt is a 6-bit counter");
+};
+
+AC_DI void ilqr_glds(const float* g, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 4, 0, 0);
+}
+// wave-level hand-off through LDS (single-wave workgroup): LDS traffic retired, no reordering across this point
+AC_DI void ilqr_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 
 template <bool NODE, bool NEWTON>  // per-node cost arrays or the constant cost; second-order dynamics blocks or none
 __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const NodeCost N, const float* __restrict__ X,
@@ -64,180 +84,240 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const No
                                                       const float* __restrict__ Bm, const float* __restrict__ Hz, long B, long H,
                                                       float* __restrict__ K, float* __restrict__ kff,
                                                       float* __restrict__ dV) {
-    __shared__ float smem[4 * kIlqrFloats];
-    const int sub = threadIdx.x >> 4, j = threadIdx.x & 15;
-    const long b_raw = (long)blockIdx.x * 4 + sub;
-    const bool live = b_raw < B;
-    const long b = live ? b_raw : B - 1;
-    float* S = smem + sub * kIlqrFloats;
-    float* sA = S;            // [13][13]
-    float* sB = S + 169;      // [13][7]
-    float* sV = S + 260;      // [13][13]
-    float* sVA = S + 429;     // [13][13]
-    float* sVB = S + 598;     // [13][7]
-    float* sQux = S + 689;    // [7][13]
-    float* sQuu = S + 780;    // [7][7]
-    float* sK = S + 829;      // [7][13]
-    float* sQxx = S + 920;    // [13] scratch column exchange (unused rows of the block are padding)
-    float* svx = S + 940;     // [13]
-    float* sqx = S + 953;     // [13]
-    float* squ = S + 966;     // [7]
-    float* skf = S + 973;     // [7]
-    (void)sQxx;
+    typedef IlqrRing<NODE, NEWTON> R;
+    __shared__ float smem[kIlqrWork + R::kDepth * R::kNodeFloats];  // ONE array: work area, then the node ring
+    float* S = smem;
+    float* ring = smem + kIlqrWork;
+    const int t = threadIdx.x, rb = t >> 4, j = t & 15;
+    const long b = blockIdx.x;  // grid = B
+    float* sV = S;            // [13][13]
+    float* sVA = S + 169;     // [13][13]
+    float* sVB = S + 338;     // [13][7]
+    float* sQux = S + 429;    // [7][13]
+    float* sQuu = S + 520;    // [7][7]
+    float* sK = S + 569;      // [7][13]
+    float* svx = S + 660;     // [13]
+    float* sqx = S + 673;     // [13]
+    float* squ = S + 686;     // [7]
 
-    // terminal condition
+    // gather node k into ring slot `slot` (wave-uniform); element e of an array lives B floats after element e-1
+    auto issue = [&](long k, int slot) {
+        float* dst = ring + slot * R::kNodeFloats;
+        const float* a = A + (k * 169) * B + b;
+        ilqr_glds(a + (long)t * B, dst);
+        ilqr_glds(a + (long)(t + 64) * B, dst + 64);
+        if (t < 169 - 128) ilqr_glds(a + (long)(t + 128) * B, dst + 128);
+        const float* bm = Bm + (k * 91) * B + b;
+        ilqr_glds(bm + (long)t * B, dst + 169);
+        if (t < 91 - 64) ilqr_glds(bm + (long)(t + 64) * B, dst + 169 + 64);
+        {   // lanes 0-12 x_k, 13-19 u_k, 20-32 q_k, 33-45 xref_k, 46-58 glin_k
+            const float* src = X + (k * 13 + t) * B + b;
+            if (t >= 13) src = U + (k * 7 + (t - 13)) * B + b;
+            if constexpr (NODE) {
+                if (t >= 20) src = N.q + (k * 13 + (t - 20)) * B + b;
+                if (t >= 33) src = N.xref + (k * 13 + (t - 33)) * B + b;
+                if (t >= 46) src = N.glin + (k * 13 + (t - 46)) * B + b;
+            }
+            if (t < (NODE ? 59 : 20)) ilqr_glds(src, dst + 260);
+        }
+        if constexpr (NEWTON) {
+            const float* hz = Hz + (k * 441) * B + b;
+#pragma unroll
+            for (int c = 0; c < 7; ++c)
+                if (c * 64 + t < 441) ilqr_glds(hz + (long)(c * 64 + t) * B, dst + 320 + c * 64);
+        }
+    };
+
+    // terminal condition (ordinary loads, before any LDS-DMA is in flight)
+    float qterm = 0.f;
     if (j < 13) {
         const float xn = X[(H * 13 + j) * B + b];
-        float qj, xr, gl;
-        N.template row<NODE>(C, H, true, j, b, qj, xr, gl);
-        svx[j] = fmaf(qj, xn - xr, gl);
-        for (int i = 0; i < 13; ++i) sV[i * 13 + j] = (i == j) ? qj : 0.f;
+        float xr, gl;
+        N.template row<NODE>(C, H, true, j, b, qterm, xr, gl);
+        if (rb == 0) svx[j] = fmaf(qterm, xn - xr, gl);
+        for (int i = rb; i < 13; i += 4) sV[i * 13 + j] = (i == j) ? qterm : 0.f;
     }
     float dv1 = 0.f, dv2 = 0.f;
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int d = 0; d < R::kDepth; ++d)
+        if (H - 1 - d >= 0) issue(H - 1 - d, d);
+    ilqr_sync();
 
-    for (long k = H - 1; k >= 0; --k) {
-        // load A_k, B_k (column j), stage gradients
-        float qjj = 0.f;  // this lane's diagonal entry of the stage Hessian
+    for (long it = 0; it < H; ++it) {
+        const long k = H - 1 - it;
+        const int slot = (int)(it % R::kDepth);
+        // node k's gather has landed once at most (kDepth - 1) younger ones are outstanding; in the tail fewer were issued
+        if (it + R::kDepth - 1 < H) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R::kInstr * (R::kDepth - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const float* nd = ring + slot * R::kNodeFloats;
+        const float* sA = nd;         // [13][13]
+        const float* sB = nd + 169;   // [13][7]
+        // stage gradients
+        float qjj = 0.f;  // diagonal entry j of the stage Hessian
         if (j < 13) {
-            for (int i = 0; i < 13; ++i) sA[i * 13 + j] = A[((k * 13 + i) * 13 + j) * B + b];
-            const float xk = X[(k * 13 + j) * B + b];
-            float xr, gl;
-            N.template row<NODE>(C, k, false, j, b, qjj, xr, gl);
-            sqx[j] = fmaf(qjj, xk - xr, gl);
+            float xr = C.x_ref[j], gl = 0.f;
+            qjj = C.q[j];
+            if constexpr (NODE) { qjj = nd[280 + j]; xr = nd[293 + j]; gl = nd[306 + j]; }
+            if (rb == 0) sqx[j] = fmaf(qjj, nd[260 + j] - xr, gl);
         }
-        if (j < 7) {
-            for (int i = 0; i < 13; ++i) sB[i * 7 + j] = Bm[((k * 13 + i) * 7 + j) * B + b];
-            squ[j] = C.r[j] * U[(k * 7 + j) * B + b];
-        }
-        __syncthreads();
-        // VA = V A, VB = V B  (column j)
+        if (j < 7 && rb == 0) squ[j] = C.r[j] * nd[273 + j];
+        ilqr_sync();
+        // VA = V A, VB = V B
         if (j < 13) {
-            for (int i = 0; i < 13; ++i) {
+            for (int i = rb; i < 13; i += 4) {
                 float s = 0.f;
+#pragma unroll
                 for (int m = 0; m < 13; ++m) s = fmaf(sV[i * 13 + m], sA[m * 13 + j], s);
                 sVA[i * 13 + j] = s;
             }
         }
         if (j < 7) {
-            for (int i = 0; i < 13; ++i) {
+            for (int i = rb; i < 13; i += 4) {
                 float s = 0.f;
+#pragma unroll
                 for (int m = 0; m < 13; ++m) s = fmaf(sV[i * 13 + m], sB[m * 7 + j], s);
                 sVB[i * 7 + j] = s;
             }
         }
-        __syncthreads();
-        // Qx, Qu, Qxx (column j, in registers), Qux (column j), Quu (column j)
-        float qxx[13];
-        float qx = 0.f;
+        ilqr_sync();
+        // Qx, Qu (per column, every row group), Qxx rows of column j (registers), Qux, Quu
+        float qxx[4] = {0.f, 0.f, 0.f, 0.f};
+        float qx = 0.f, qu = 0.f;
+        const float* hz = nd + 320;  // [21][21] (NEWTON only)
         if (j < 13) {
             qx = sqx[j];
+#pragma unroll
             for (int m = 0; m < 13; ++m) qx = fmaf(sA[m * 13 + j], svx[m], qx);
-            // Hz (optional): second-order dynamics terms  sum_i lambda_i d2F_i/dz dz  of this node, z = (x, u, dt)
-            const float* hz = NEWTON ? Hz + (k * 441) * B + b : nullptr;
-            for (int i = 0; i < 13; ++i) {
+            for (int i = rb, n = 0; i < 13; i += 4, ++n) {
                 float s = (i == j) ? qjj : 0.f;
-                if constexpr (NEWTON) s += hz[((long)i * 21 + j) * B];
+                if constexpr (NEWTON) s += hz[i * 21 + j];
+#pragma unroll
                 for (int m = 0; m < 13; ++m) s = fmaf(sA[m * 13 + i], sVA[m * 13 + j], s);
-                qxx[i] = s;
+                qxx[n] = s;
             }
-            for (int i = 0; i < 7; ++i) {
-                float s = NEWTON ? hz[((long)(13 + i) * 21 + j) * B] : 0.f;
+            for (int i = rb; i < 7; i += 4) {
+                float s = NEWTON ? hz[(13 + i) * 21 + j] : 0.f;
+#pragma unroll
                 for (int m = 0; m < 13; ++m) s = fmaf(sB[m * 7 + i], sVA[m * 13 + j], s);
                 sQux[i * 13 + j] = s;
             }
         }
         if (j < 7) {
-            float qu = squ[j];
+            qu = squ[j];
+#pragma unroll
             for (int m = 0; m < 13; ++m) qu = fmaf(sB[m * 7 + j], svx[m], qu);
-            squ[j] = qu;  // now holds Qu
-            for (int i = 0; i < 7; ++i) {
+            for (int i = rb; i < 7; i += 4) {
                 float s = (i == j) ? C.r[j] + C.reg : 0.f;
-                if constexpr (NEWTON) s += Hz[((k * 21 + 13 + i) * 21 + 13 + j) * B + b];
+                if constexpr (NEWTON) s += hz[(13 + i) * 21 + 13 + j];
+#pragma unroll
                 for (int m = 0; m < 13; ++m) s = fmaf(sB[m * 7 + i], sVB[m * 7 + j], s);
                 sQuu[i * 7 + j] = s;
             }
         }
-        __syncthreads();
+        ilqr_sync();  // Qux, Quu complete; sqx / squ / svx fully read
+        if (j < 7 && rb == 0) squ[j] = qu;  // now holds Qu
+        ilqr_sync();
         // Cholesky Quu = L L' (every lane, in registers), then K(:, j) = -Quu^-1 Qux(:, j), kff = -Quu^-1 Qu
         float L[7][7];
+#pragma unroll
         for (int i = 0; i < 7; ++i)
+#pragma unroll
             for (int m = 0; m <= i; ++m) {
                 float s = 0.5f * (sQuu[i * 7 + m] + sQuu[m * 7 + i]);
+#pragma unroll
                 for (int p = 0; p < m; ++p) s -= L[i][p] * L[m][p];
                 L[i][m] = (i == m) ? sqrtf(fmaxf(s, 1e-12f)) : s / L[m][m];
             }
         auto solve = [&](float rhs[7]) {  // in place: rhs <- Quu^-1 rhs
+#pragma unroll
             for (int i = 0; i < 7; ++i) {
                 float s = rhs[i];
+#pragma unroll
                 for (int p = 0; p < i; ++p) s -= L[i][p] * rhs[p];
                 rhs[i] = s / L[i][i];
             }
+#pragma unroll
             for (int i = 6; i >= 0; --i) {
                 float s = rhs[i];
+#pragma unroll
                 for (int p = i + 1; p < 7; ++p) s -= L[p][i] * rhs[p];
                 rhs[i] = s / L[i][i];
             }
         };
-        float kf[7];
-        for (int i = 0; i < 7; ++i) kf[i] = squ[i];
+        float kf[7], quv[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { quv[i] = squ[i]; kf[i] = quv[i]; }
         solve(kf);
+#pragma unroll
         for (int i = 0; i < 7; ++i) kf[i] = -kf[i];
-        float kcol[7];
+        float kcol[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (j < 13) {
+#pragma unroll
             for (int i = 0; i < 7; ++i) kcol[i] = sQux[i * 13 + j];
             solve(kcol);
-            for (int i = 0; i < 7; ++i) { kcol[i] = -kcol[i]; sK[i * 13 + j] = kcol[i]; }
-            if (live)
-                for (int i = 0; i < 7; ++i) K[((k * 7 + i) * 13 + j) * B + b] = kcol[i];
-        }
-        if (j == 0) {
-            for (int i = 0; i < 7; ++i) {
-                skf[i] = kf[i];
-                if (live) kff[(k * 7 + i) * B + b] = kf[i];
-                dv1 += kf[i] * squ[i];
-                float s = 0.f;
-                for (int m = 0; m < 7; ++m) s += 0.5f * (sQuu[i * 7 + m] + sQuu[m * 7 + i]) * kf[m];
-                dv2 += 0.5f * kf[i] * s;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) kcol[i] = -kcol[i];
+            if (rb == 0) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) { sK[i * 13 + j] = kcol[i]; K[((k * 7 + i) * 13 + j) * B + b] = kcol[i]; }
             }
         }
-        __syncthreads();
-        // V_x(j) = Qx + K' Quu kff + K' Qu + Qux' kff ;  V_xx(:, j) = Qxx + K' Quu K + K' Qux + Qux' K
-        float vx = 0.f, vcol[13];
-        if (j < 13) {
-            float quuk[7], quukf[7];  // Quu K(:, j), Quu kff
+        float quukf[7];  // Quu kff (every lane)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int m = 0; m < 7; ++m) t = fmaf(0.5f * (sQuu[i * 7 + m] + sQuu[m * 7 + i]), kf[m], t);
+            quukf[i] = t;
+        }
+        if (threadIdx.x == 0) {
+#pragma unroll
             for (int i = 0; i < 7; ++i) {
-                float s = 0.f, t = 0.f;
-                for (int m = 0; m < 7; ++m) {
-                    const float qs = 0.5f * (sQuu[i * 7 + m] + sQuu[m * 7 + i]);
-                    s = fmaf(qs, kcol[m], s);
-                    t = fmaf(qs, kf[m], t);
-                }
-                quuk[i] = s; quukf[i] = t;
+                kff[(k * 7 + i) * B + b] = kf[i];
+                dv1 += kf[i] * quv[i];
+                dv2 += 0.5f * kf[i] * quukf[i];
+            }
+        }
+        ilqr_sync();  // sK visible
+        // V_x(j) = Qx + K' Quu kff + K' Qu + Qux' kff ;  V_xx(i, j) = Qxx + K' Quu K + K' Qux + Qux' K
+        float vx = 0.f, vrow[4] = {0.f, 0.f, 0.f, 0.f};
+        if (j < 13) {
+            float quuk[7];  // Quu K(:, j)
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int m = 0; m < 7; ++m) s = fmaf(0.5f * (sQuu[i * 7 + m] + sQuu[m * 7 + i]), kcol[m], s);
+                quuk[i] = s;
             }
             vx = qx;
-            for (int i = 0; i < 7; ++i) vx += kcol[i] * (quukf[i] + squ[i]) + sQux[i * 13 + j] * kf[i];
-            for (int i = 0; i < 13; ++i) {
-                float s = qxx[i];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) vx += kcol[i] * (quukf[i] + quv[i]) + sQux[i * 13 + j] * kf[i];
+            for (int i = rb, n = 0; i < 13; i += 4, ++n) {
+                float s = qxx[n];
+#pragma unroll
                 for (int m = 0; m < 7; ++m) s += sK[m * 13 + i] * (quuk[m] + sQux[m * 13 + j]) + sQux[m * 13 + i] * kcol[m];
-                vcol[i] = s;
+                vrow[n] = s;
             }
         }
-        __syncthreads();  // every lane has read the old V / Qu before they are overwritten
+        ilqr_sync();  // every lane has read the old V / Qux before they are overwritten
         if (j < 13) {
-            svx[j] = vx;
-            for (int i = 0; i < 13; ++i) sV[i * 13 + j] = vcol[i];
+            if (rb == 0) svx[j] = vx;
+            for (int i = rb, n = 0; i < 13; i += 4, ++n) sV[i * 13 + j] = vrow[n];
         }
-        __syncthreads();
-        // symmetrise V (each lane fixes its column against the transpose)
+        ilqr_sync();
+        // symmetrise V: entry (i, j) <- mean with (j, i); both read before either is written
+        float sym[4] = {0.f, 0.f, 0.f, 0.f};
         if (j < 13)
-            for (int i = 0; i < 13; ++i) vcol[i] = 0.5f * (sV[i * 13 + j] + sV[j * 13 + i]);
-        __syncthreads();
+            for (int i = rb, n = 0; i < 13; i += 4, ++n) sym[n] = 0.5f * (sV[i * 13 + j] + sV[j * 13 + i]);
+        ilqr_sync();
         if (j < 13)
-            for (int i = 0; i < 13; ++i) sV[i * 13 + j] = vcol[i];
-        __syncthreads();
+            for (int i = rb, n = 0; i < 13; i += 4, ++n) sV[i * 13 + j] = sym[n];
+        ilqr_sync();
+        if (k - R::kDepth >= 0) issue(k - R::kDepth, slot);  // every read of this slot has retired (lgkmcnt(0) above)
     }
-    if (live && j == 0) { dV[b] = dv1; dV[B + b] = dv2; }
+    if (threadIdx.x == 0) { dV[b] = dv1; dV[B + b] = dv2; }
 }
 
 // ---- costate sweep ------------------------------------------------------------------------------------

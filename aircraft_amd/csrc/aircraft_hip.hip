@@ -633,7 +633,7 @@ int ac_ilqr_backward_newton_f32(ac_handle* h, const ac_ilqr_cost* cost, const fl
     if ((node_q || node_xref || node_glin) && !(node_q && node_xref && node_glin)) return AC_ERR_BAD_ARG;
     const NodeCost nc{node_q, node_xref, node_glin, B};
     hipStream_t st = (hipStream_t)stream;
-    const int grid = (int)((B + 3) / 4);
+    const int grid = (int)B;  // one wave per instance
 #define AC_BACKWARD(NODE_, NEWTON_) \
     hipLaunchKernelGGL((k_ilqr_backward<NODE_, NEWTON_>), grid, 64, 0, st, to_dev_cost(cost), nc, X, U, A, Bm, Hz, B, H, K, kff, dV)
     if (node_q && Hz) AC_BACKWARD(true, true);
@@ -641,7 +641,7 @@ int ac_ilqr_backward_newton_f32(ac_handle* h, const ac_ilqr_cost* cost, const fl
     else if (Hz) AC_BACKWARD(false, true);
     else AC_BACKWARD(false, false);
 #undef AC_BACKWARD
-    note_launch(h, "k_ilqr_backward", grid, 64, 4 * kIlqrFloats * 4);
+    note_launch(h, "k_ilqr_backward", grid, 64, 0);
     AC_HIP(hipGetLastError());
     return AC_OK;
 }
