@@ -18,13 +18,13 @@ struct WaveUnit {
     long unit;
     bool live;
     UnitAddr ua;
-    AC_DI static long raw_unit() {
-        return ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 15);
+    AC_DI static long raw_unit(long unit0) {
+        return unit0 + ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 15);
     }
-    // dead lanes shadow the last unit so wave/workgroup collectives stay uniform
-    AC_DI WaveUnit(long n, long blk)
+    // units [unit0, n) of the batch; dead lanes shadow the last unit so wave/workgroup collectives stay uniform
+    AC_DI WaveUnit(long n, long blk, long unit0 = 0)
         : lane(threadIdx.x & 63), col(threadIdx.x & 15), g((threadIdx.x & 63) >> 4),
-          unit(raw_unit() < n ? raw_unit() : n - 1), live(raw_unit() < n), ua(unit, blk) {}
+          unit(raw_unit(unit0) < n ? raw_unit(unit0) : n - 1), live(raw_unit(unit0) < n), ua(unit, blk) {}
 };
 
 template <int WT, bool USE_MFMA>
@@ -73,11 +73,11 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_fwd(const DevParams P, const M
                                                       const float* __restrict__ blob, const float* __restrict__ X,
                                                       const float* __restrict__ U, float dt,
                                                       const float* __restrict__ dt_per_unit, long n, long blk,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, long unit0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MlpEngine<1, WT, USE_MFMA> eng(plan, blob, smem);
     eng.load_weights();
-    const WaveUnit w(n, blk);
+    const WaveUnit w(n, blk, unit0);  // this launch covers units [unit0, n)
     float x[13], u[7];
     load_rows<13>(X, w.ua, x);
     load_rows<7>(U, w.ua, u);
@@ -117,12 +117,12 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_fwd4(const DevParams P, const 
                                                        const float* __restrict__ blob, const float* __restrict__ X,
                                                        const float* __restrict__ U, float dt,
                                                        const float* __restrict__ dt_per_unit, long n, long blk,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, long unit0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef MlpEngine<4, WT, true, false> Engine;
     Engine eng(plan, blob, smem);
     eng.load_weights();
-    const long raw = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long raw = unit0 + (long)blockIdx.x * kBlock + threadIdx.x;  // this launch covers units [unit0, n)
     const bool live = raw < n;
     const long unit = live ? raw : n - 1;  // dead lanes shadow the last unit: the engine is wave/workgroup-collective
     const UnitAddr ua(unit, blk);

@@ -57,6 +57,7 @@ constexpr int kLdsBudget = 160 * 1024;  // gfx950 LDS per workgroup
 struct ac_handle {
     DevParams dp;
     int device;
+    int num_cus;
     bool has_linear, has_poly, has_mlp;
     MlpPlan plan;
     int wt;         // register tiles per slab the plan needs (2, 4 or 8)
@@ -172,6 +173,10 @@ int ac_create(const ac_params* params, ac_handle** out) {
     memset(h, 0, sizeof(*h));
     h->dp.p = *params;
     AC_HIP(hipGetDevice(&h->device));
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess) h->num_cus = cus;
+    }
     *out = h;
     return AC_OK;
 }
@@ -314,17 +319,30 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
 static int launch_nn_fwd(ac_handle* h, int op, const float* X, const float* U, float dt, const float* dtp, long n,
                          long blk, float* out, hipStream_t st) {
     bool launched = false;
-    // Four value slabs per wave (k_nn_fwd4) amortise the per-layer fixed costs (measured: a 256-unit workgroup takes
-    // 3.4x the time of a 64-unit one) but quarter the number of workgroups; pick it when whole rounds over the 256 CUs
-    // come out cheaper, i.e. for large n where the tail of the last round does not eat the gain.
-    const long rounds1 = ((n + 63) / 64 + 255) / 256, rounds4 = ((n + 255) / 256 + 255) / 256;
-    if (h->use_mfma && 3.4 * (double)rounds4 < (double)rounds1) {
-        const int grid4 = (int)((n + kBlock - 1) / kBlock);
+    // Two kernels: k_nn_fwd (16 units per wave, 64 per workgroup) and k_nn_fwd4 (four value slabs per wave, 256 units per
+    // workgroup: the per-layer fixed costs are shared, measured 3.4x the time of a 64-unit workgroup for 4x the units).
+    // One workgroup per CU is resident, so time goes in whole ROUNDS over the CUs and the last, partly filled round costs
+    // as much as a full one.  Split the batch: the units that fill whole rounds of k_nn_fwd4 go there, the remainder
+    // (less than one such round) runs in the cheaper rounds of k_nn_fwd; take whichever of {all fwd, all fwd4, split}
+    // has the lowest modelled cost (in k_nn_fwd rounds).
+    const long cus = h->num_cus > 0 ? h->num_cus : 256;
+    const double kFwd4Round = 3.4;
+    auto rounds = [&](long units, long per_wg) { return (double)(((units + per_wg - 1) / per_wg + cus - 1) / cus); };
+    const long full4 = h->use_mfma ? (n / (256 * cus)) * (256 * cus) : 0;
+    const double cost_fwd = rounds(n, 64), cost_fwd4 = h->use_mfma ? kFwd4Round * rounds(n, 256) : 1e30;
+    const double cost_split = (full4 > 0 && full4 < n) ? kFwd4Round * (double)(full4 / (256 * cus)) + rounds(n - full4, 64) + 0.05
+                                                       : 1e30;
+    long n4 = 0;  // units [0, n4) take k_nn_fwd4, [n4, n) take k_nn_fwd
+    if (cost_fwd4 <= cost_fwd && cost_fwd4 <= cost_split) n4 = n;
+    else if (cost_split < cost_fwd) n4 = full4;
+    if (n4 > 0) {
+        const int grid4 = (int)((n4 + kBlock - 1) / kBlock);
+        const long zero = 0;
 #define AC_FWD4_CASE(WT_)                                                                                        \
         if (h->wt == WT_) {                                                                                      \
-            if (op == OP_DERIV) { AC_NN_CASE(WT_, true, (k_nn_fwd4<WT_, OP_DERIV>), grid4, kBlock, X, U, dt, dtp, n, blk, out) } \
-            else if (op == OP_STEP) { AC_NN_CASE(WT_, true, (k_nn_fwd4<WT_, OP_STEP>), grid4, kBlock, X, U, dt, dtp, n, blk, out) } \
-            else { AC_NN_CASE(WT_, true, (k_nn_fwd4<WT_, OP_AERO>), grid4, kBlock, X, U, dt, dtp, n, blk, out) }    \
+            if (op == OP_DERIV) { AC_NN_CASE(WT_, true, (k_nn_fwd4<WT_, OP_DERIV>), grid4, kBlock, X, U, dt, dtp, n4, blk, out, zero) } \
+            else if (op == OP_STEP) { AC_NN_CASE(WT_, true, (k_nn_fwd4<WT_, OP_STEP>), grid4, kBlock, X, U, dt, dtp, n4, blk, out, zero) } \
+            else { AC_NN_CASE(WT_, true, (k_nn_fwd4<WT_, OP_AERO>), grid4, kBlock, X, U, dt, dtp, n4, blk, out, zero) }    \
         }
         AC_FWD4_CASE(2) AC_FWD4_CASE(4) AC_FWD4_CASE(8)
 #undef AC_FWD4_CASE
@@ -332,19 +350,21 @@ static int launch_nn_fwd(ac_handle* h, int op, const float* X, const float* U, f
         note_launch(h, op == OP_DERIV ? "k_nn_fwd4<deriv>" : (op == OP_STEP ? "k_nn_fwd4<step>" : "k_nn_fwd4<aero>"), grid4,
                     kBlock, h->plan.lds_total);
         AC_HIP(hipGetLastError());
-        return AC_OK;
+        if (n4 == n) return AC_OK;
+        launched = false;
     }
-    const int grid = (int)((n + 63) / 64);
+    const int grid = (int)((n - n4 + 63) / 64);
 #define AC_FWD_OPS(WT_, MF_)                                                                                   \
-    if (op == OP_DERIV) { AC_NN_CASE(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_DERIV>), grid, kBlock, X, U, dt, dtp, n, blk, out) } \
-    else if (op == OP_STEP) { AC_NN_CASE(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_STEP>), grid, kBlock, X, U, dt, dtp, n, blk, out) } \
-    else { AC_NN_CASE(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_AERO>), grid, kBlock, X, U, dt, dtp, n, blk, out) }
+    if (op == OP_DERIV) { AC_NN_CASE(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_DERIV>), grid, kBlock, X, U, dt, dtp, n, blk, out, n4) } \
+    else if (op == OP_STEP) { AC_NN_CASE(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_STEP>), grid, kBlock, X, U, dt, dtp, n, blk, out, n4) } \
+    else { AC_NN_CASE(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_AERO>), grid, kBlock, X, U, dt, dtp, n, blk, out, n4) }
     AC_FWD_OPS(2, true) AC_FWD_OPS(4, true) AC_FWD_OPS(8, true)
     AC_FWD_OPS(2, false) AC_FWD_OPS(4, false) AC_FWD_OPS(8, false)
 #undef AC_FWD_OPS
     if (!launched) return AC_ERR_UNSUPPORTED;
-    note_launch(h, op == OP_DERIV ? "k_nn_fwd<deriv>" : (op == OP_STEP ? "k_nn_fwd<step>" : "k_nn_fwd<aero>"), grid,
-                kBlock, h->plan.lds_total);
+    if (n4 == 0)
+        note_launch(h, op == OP_DERIV ? "k_nn_fwd<deriv>" : (op == OP_STEP ? "k_nn_fwd<step>" : "k_nn_fwd<aero>"), grid,
+                    kBlock, h->plan.lds_total);
     AC_HIP(hipGetLastError());
     return AC_OK;
 }
