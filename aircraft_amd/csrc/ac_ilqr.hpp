@@ -407,6 +407,49 @@ struct Policy {
             u[i] = fminf(fmaxf(s, u_min[i]), u_max[i]);
         }
     }
+
+    // The same control law for kernels where the four lane groups g = 0..3 of a wave hold the same instance (MLP
+    // rollouts): group g takes the columns m = g, g+4, g+8, g+12 of K_k, so a lane loads a quarter of the gains, and
+    // the partial products are summed across the groups with two cross-lane adds.  load() can be issued a node ahead.
+    struct Quarter {
+        float kq[7][4], xn[4], ub[7];
+    };
+    AC_DI void load(long k, long o, int g, Quarter& q) const {
+        const long b = o % B;
+        const float alpha = alphas.a[(int)(o / B)];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int m = g + 4 * c;
+            const bool on = m < 13;
+            const int mm = on ? m : 12;
+            q.xn[c] = Xnom[(k * 13 + mm) * B + b];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) q.kq[i][c] = on ? K[((k * 7 + i) * 13 + mm) * B + b] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) q.ub[i] = fmaf(alpha, kff[(k * 7 + i) * B + b], U[(k * 7 + i) * B + b]);
+    }
+    AC_DI void control(const Quarter& q, int g, const float x[13], float u[7]) const {
+        float dx[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            // x[g + 4 c] without dynamic register indexing (c == 3 only exists for g == 0)
+            const float x0 = x[4 * c], x1 = (4 * c + 1 < 13) ? x[(4 * c + 1 < 13) ? 4 * c + 1 : 0] : 0.f;
+            const float x2 = (4 * c + 2 < 13) ? x[(4 * c + 2 < 13) ? 4 * c + 2 : 0] : 0.f;
+            const float x3 = (4 * c + 3 < 13) ? x[(4 * c + 3 < 13) ? 4 * c + 3 : 0] : 0.f;
+            const float xs = g == 0 ? x0 : (g == 1 ? x1 : (g == 2 ? x2 : x3));
+            dx[c] = xs - q.xn[c];
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s = fmaf(q.kq[i][c], dx[c], s);
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            u[i] = fminf(fmaxf(q.ub[i] + s, u_min[i]), u_max[i]);
+        }
+    }
 };
 
 // closed-loop rollout, analytic models: one lane per output instance

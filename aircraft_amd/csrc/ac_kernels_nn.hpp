@@ -277,10 +277,13 @@ AC_DI void rollout_policy_body(const DevParams& P, const MlpPlan& plan, const fl
         for (int r = 0; r < 13; ++r) Xout[(long)r * Bout + o] = x[r];
     }
     MlpCoeffs<Engine> coeffs(eng);
+    Policy::Quarter q, qn;  // this lane group's quarter of the gains: node k, and node k+1 prefetched during the step
+    if (H > 0) pol.load(0, o, g, q);
     for (long k = 0; k < H; ++k) {
 #pragma unroll
         for (int r = 0; r < 13; ++r) x[r] = (float)xa[r];
-        pol.control(k, o, x, u);
+        pol.control(q, g, x, u);
+        if (k + 1 < H) pol.load(k + 1, o, g, qn);
         if (writer) {
 #pragma unroll
             for (int r = 0; r < 7; ++r) Uout[(k * 7 + r) * Bout + o] = u[r];
@@ -291,6 +294,7 @@ AC_DI void rollout_policy_body(const DevParams& P, const MlpPlan& plan, const fl
 #pragma unroll
             for (int r = 0; r < 13; ++r) out[(long)r * Bout + o] = (float)xa[r];
         }
+        q = qn;
     }
     eng.drain();
 }
