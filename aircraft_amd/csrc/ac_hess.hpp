@@ -4,8 +4,8 @@
 // control/base.py:279-280 contribute  -lambda_k' d2F/dz2  per node; todo.md:102 names it the largest time sink).
 // Exact second-order forward mode of the same arithmetic as the step kernels: every scalar carries
 //   v, a = d/d(alpha), d[j] = d/d(beta_j), h[j] = d2/d(alpha)d(beta_j)
-// for one "outer" direction alpha and N "inner" directions beta_j.  A unit's 16 x 16 direction pairs are spread over
-// 16 * (16/N) lanes (direction layout as in SeedsT: 0-9 = v, q, omega; 10-13 = active controls; 14 = dt; 15 unused);
+// for one "outer" direction alpha and N "inner" directions beta_j.  A unit's direction pairs (upper triangle of
+// 16 x 16, by blocks of N) are spread over N (16/N)(16/N + 1)/2 - 1 lanes (direction layout as in SeedsT: 0-9 = v, q, omega; 10-13 = active controls; 14 = dt; 15 unused);
 // the primal is recomputed by every lane.  Analytic force models only (default / linear / poly / quadrotor); one RK4
 // sub-step (what every MPC driver of the reference uses).  d2F/dp.. = 0 and dead controls have no rows: the caller's
 // output is zero-filled and only the active 15 x 15 block is written.
@@ -185,6 +185,8 @@ template <int N, bool QUAD> AC_DI Jet2<N> hess_seed(int a, int g, int dir, float
     return r;
 }
 
+template <int N> struct HessTasks { static constexpr int value = N * (16 / N) * (16 / N + 1) / 2 - 1; };  // lanes per unit
+
 // H[za][zb][unit] = sum_i lambda_i d2F_i / dz_a dz_b, active block only (the ABI zero-fills the rest beforehand).
 template <int MODEL, int N>
 __global__ __launch_bounds__(kBlock) void k_step_hess(const DevParams P, const float* __restrict__ X,
@@ -194,13 +196,16 @@ __global__ __launch_bounds__(kBlock) void k_step_hess(const DevParams P, const f
                                                       const float* __restrict__ stage_tensors, long n, long blk,
                                                       float* __restrict__ Hout) {
     constexpr bool QUAD = MODEL == AC_MODEL_QUAD;
-    constexpr int G = 16 / N;        // inner groups
-    constexpr int LPU = 16 * G;      // lanes per unit
-    constexpr int UPB = kBlock / LPU;
+    constexpr int G = 16 / N;  // inner groups
     typedef Jet2<N> T;
-    const int t = threadIdx.x % LPU;
-    const int a = t / G, g = t % G;
-    const long unit_raw = (long)blockIdx.x * UPB + threadIdx.x / LPU;
+    // The Hessian is symmetric: only the tasks (a, g) whose inner block reaches the diagonal (N g + N - 1 >= a) run, and
+    // an off-diagonal block is written to both triangles.  Tasks are ordered by the block A = a / N of the outer
+    // direction, then r = a % N, then g = A .. G-1; the unused direction 15 is the last task and is dropped.
+    const long gt = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long unit_raw = gt / HessTasks<N>::value;
+    int rem = (int)(gt % HessTasks<N>::value), A = 0;
+    while (rem >= N * (G - A)) { rem -= N * (G - A); ++A; }
+    const int a = N * A + rem / (G - A), g = A + rem % (G - A);
     const bool live = unit_raw < n;
     const long unit = live ? unit_raw : n - 1;
     const UnitAddr ua(unit, blk);
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(kBlock) void k_step_hess(const DevParams P, const f
 #pragma unroll
         for (int i = 0; i < 13; ++i) s = fmaf(lam[i], xo[i].h[j], s);
         Hu[((long)za * 21 + zb) * blk] = s;
+        if (g != A) Hu[((long)zb * 21 + za) * blk] = s;  // the mirrored task does not run
     }
 }
 

@@ -114,8 +114,8 @@ template <int MODEL>
 void launch_hess(ac_handle* h, hipStream_t st, const float* X, const float* U, float dt, const float* dt_per_unit,
                         const float* Lam, long n, long blk, float* Hout, int* grid_out) {
     constexpr int N = HessN<MODEL>::value;
-    constexpr int upb = kBlock / (16 * (16 / N));  // units per workgroup
-    const int grid = (int)((n + upb - 1) / upb);
+    const long lanes = n * HessTasks<N>::value;  // upper-triangle tasks of every unit, packed across workgroups
+    const int grid = (int)((lanes + kBlock - 1) / kBlock);
     hipLaunchKernelGGL((k_step_hess<MODEL, N>), grid, kBlock, 0, st, h->dp, X, U, dt, dt_per_unit, Lam,
                        (const float*)h->d_hess_ws, n, blk, Hout);
     *grid_out = grid;
