@@ -46,18 +46,21 @@ class RecedingHorizon:
         self.x0 = x0.clone().contiguous()
         self.U = U0.clone().contiguous()
         self.X = torch.empty((H + 1, 13, B), device=x0.device, dtype=torch.float32)
+        self._Xhead = torch.empty((self.overlap + 1, 13, B), device=x0.device, dtype=torch.float32)
+        self.executed = torch.empty((self.keep, 13, B), device=x0.device, dtype=torch.float32)  # states 1..keep of the last solve
         self.cost = torch.empty((B,), device=x0.device, dtype=torch.float32)
         self.solver._workspace(B, x0.device)
+        self.solver.rollout(self.x0, self.U, out=self.X)  # every cycle ends with X prepared for the next one
         return self
 
     def cycle(self):
         """One solve + shift on the allocated buffers (capturable: no allocation, no host sync)."""
         torch = _torch()
         s = self.solver
-        s.rollout(self.x0, self.U, out=self.X)
         for _ in range(self.iterations):
             J, _ = s.iterate(self.x0, self.X, self.U)
         self.cost.copy_(J)
+        self.executed.copy_(self.X[1 : self.keep + 1])
         # advance: the state reached after the kept nodes becomes the next initial state
         self.x0.copy_(self.X[self.keep])
         if hasattr(s, "advance_progress"):  # MHTT: the progress reached at the last kept node (mhtt.py:105)
@@ -66,8 +69,15 @@ class RecedingHorizon:
             tail = self.U[self.keep:].clone()
             self.U[: self.overlap].copy_(tail)
             self.U[self.overlap:].copy_(tail[-1:].expand(self.keep, -1, -1))
+            # the accepted X is the rollout of U, so the shifted window already has its first `overlap` nodes; only the
+            # `keep` new ones at the end are integrated, from the old final state
+            self._Xhead.copy_(self.X[self.keep:])
+            self.X[: self.overlap + 1].copy_(self._Xhead)
+            if self.keep > 0:
+                s.rollout(self.X[self.overlap], self.U[self.overlap:], out=self.X[self.overlap:])
         else:
             self.U.zero_()
+            s.rollout(self.x0, self.U, out=self.X)
 
     def capture(self):
         """Capture one cycle into a hipGraph; afterwards step() replays it."""
@@ -75,18 +85,18 @@ class RecedingHorizon:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            x0, U = self.x0.clone(), self.U.clone()
+            x0, U, X = self.x0.clone(), self.U.clone(), self.X.clone()
             s0 = getattr(self.solver, "s0", None)  # MHTT carries the progress at node 0 across cycles
             s0_saved = s0.clone() if s0 is not None else None
             self.cycle()  # warm-up launch outside capture (lazy initialisation, LDS attribute calls)
             torch.cuda.synchronize()
-            self.x0.copy_(x0); self.U.copy_(U)
+            self.x0.copy_(x0); self.U.copy_(U); self.X.copy_(X)
             if s0 is not None:
                 s0.copy_(s0_saved)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
                 self.cycle()
-            self.x0.copy_(x0); self.U.copy_(U)
+            self.x0.copy_(x0); self.U.copy_(U); self.X.copy_(X)
             if s0 is not None:
                 s0.copy_(s0_saved)
         torch.cuda.current_stream().wait_stream(side)
@@ -107,8 +117,7 @@ class RecedingHorizon:
             x_before = self.x0.clone() if record else None
             self.step()
             if record:
-                # X still holds the trajectory of this solve: its first `keep` steps were executed
-                hist.append(self.X[1 : self.keep + 1].clone())
+                hist.append(self.executed.clone())  # the first `keep` steps of this solve were executed
                 del x_before
         return torch.cat(hist) if record else None
 

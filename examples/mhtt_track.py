@@ -83,7 +83,7 @@ def main():
     t0 = time.perf_counter()
     while cycles < args.max_cycles:
         loop.step()
-        states.append(loop.X[1 : keep + 1].clone())
+        states.append(loop.executed.clone())
         ref, _ = mhtt.track_eval(mhtt.s0)  # where each glider should be vs where it is, at the hand-over node
         dists.append((loop.x0[:3] - ref).norm(dim=0))
         cycles += 1
