@@ -57,6 +57,13 @@ def cpu_baseline(ac, X, U, dt, seconds):
     from tests.helpers import make_oracle
 
     o = make_oracle(ac)
+    # threads actually usable by this process (affinity mask), not every core the host shows
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    if usable < orc.num_threads():
+        orc.set_num_threads(usable)
     cores = orc.num_threads()
     n_probe = min(X.shape[1], 64 * cores)
     t0 = time.perf_counter()
