@@ -155,12 +155,12 @@ class MHTT(ILQR):
 
     def __init__(self, *, system, track: Track, dt: float, num_nodes: int, opts: Optional[dict] = None,
                  weights: Optional[MHTTWeights] = None, reg: float = 1.0,
-                 alphas: Sequence[float] = (1.0, 0.5, 0.25, 0.1, 0.03), **kwargs):
+                 alphas: Sequence[float] = (1.0, 0.5, 0.25, 0.1, 0.03), hessian: str = "gauss-newton", **kwargs):
         opts = opts if opts else {"time": "fixed", "quaternion": "integration", "integration": "explicit"}
         assert opts.get("time", "fixed") == "fixed", "can only run mhtt with fixed time"  # moving_horizon.py:35
         self.weights = weights or MHTTWeights()
         cost = QuadraticCost(r=[2.0 * self.weights.w_control] * 7, reg=reg)  # w_control * |u|^2 = 1/2 u' (2 w) u
-        super().__init__(system=system, dt=dt, num_nodes=num_nodes, cost=cost, opts=opts, alphas=alphas)
+        super().__init__(system=system, dt=dt, num_nodes=num_nodes, cost=cost, opts=opts, alphas=alphas, hessian=hessian)
         self.track = track
         self.track_length = track.length()
         assert self.track_length > 1e-6  # moving_horizon.py:155

@@ -160,6 +160,21 @@ def test_mhtt_solve_improves_true_loss(gpu, model, hidden, B):
     assert (f64(te1)[-1] < f64(te0)[-1]).mean() > 0.7
 
 
+def test_mhtt_with_exact_dynamics_hessian(gpu):
+    """The Newton variant of the sweep under the per-node MHTT cost model: the costate uses the node arrays, the
+    second-order dynamics blocks enter the Riccati pass, acceptance stays on the true loss (monotone)."""
+    from aircraft_amd.control import MHTT
+
+    ac, mh, tro, X0, U, s0 = setup(gpu, B=48, H=30)
+    newton = MHTT(system=ac, track=mh.track, dt=0.01, num_nodes=30, alphas=(1.0, 0.5, 0.1), hessian="exact")
+    X, Uo, S, hist = newton.solve(dev(X0, gpu), dev(s0, gpu), dev(np.zeros_like(U), gpu), iters=4)
+    h = f64(hist)
+    assert np.isfinite(h).all() and (np.diff(h, axis=0) <= 1e-6 * np.abs(h[:-1]) + 1e-5).all()
+    assert (h[-1] < h[0]).mean() > 0.8
+    _, _, _, hist_gn = mh.solve(dev(X0, gpu), dev(s0, gpu), dev(np.zeros_like(U), gpu), iters=4)
+    assert np.median(np.abs(h[-1] - f64(hist_gn)[-1]) / np.abs(f64(hist_gn)[-1])) < 0.05  # same minimum
+
+
 def test_receding_horizon_on_the_track_eager_equals_graph(gpu):
     """The closed loop of main/mhe/mhtt.py:79-124 with the track: solve, keep N - overlap nodes, restart from the last
     kept state AND its progress.  Captured into a hipGraph the loop must reproduce the eager run."""
