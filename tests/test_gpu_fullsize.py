@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from tests.helpers import block_rel_err, f32_exact, make_aircraft, make_oracle, rel_fro
-from aircraft_amd.synthetic import synthetic_controls, synthetic_states
+from aircraft_amd.synthetic import synthetic_controls, synthetic_states, synthetic_units
 
 pytestmark = pytest.mark.gpu
 
@@ -197,3 +197,41 @@ def test_forward_64_units_per_wave_path(gpu, hidden):
     dt = np.random.default_rng(0).uniform(1e-3, 1e-2, n)
     out2 = ac.state_update(Xd, Ud, torch.from_numpy(dt).float().to(gpu)).cpu().numpy()
     assert block_rel_err(out2[:, idx], orc.state_update(X[:, idx], U[:, idx], f32_exact(dt)[idx])) < 1e-5
+
+
+@pytest.mark.parametrize("model,hidden", [("default", None), ("nn", (32, 32))])
+def test_indexing_beyond_2_31_elements(gpu, model, hidden):
+    """Maximum sizes: 13 M units make dF/dx a 2.2e9-element array (8.8 GB), past 32-bit element indices.  The inputs
+    are a small set repeated, so every output must repeat with the same period — checked at the start, the middle and
+    the very end of the arrays, and against the small call itself."""
+    import torch
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40e9:
+        pytest.skip("needs ~20 GB of device memory")
+    ac = make_aircraft(model, hidden=hidden, normalise=True)
+    P, reps = 4096, 3175  # 13 004 800 units
+    n = P * reps
+    X, U = synthetic_units(P, seed=77)
+    Xs = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(gpu)
+    Us = torch.from_numpy(np.ascontiguousarray(U, dtype=np.float32)).to(gpu)
+    ref = ac.step_sens(Xs, Us, 0.01)
+    Xb, Ub = Xs.repeat(1, reps), Us.repeat(1, reps)
+    assert Xb.shape == (13, n)
+    out = ac.step_sens(Xb, Ub, 0.01)
+    assert out[1].numel() > 2 ** 31
+    for got, want in zip(out, ref):
+        for start in (0, (reps // 2) * P, (reps - 1) * P):
+            assert torch.equal(got[..., start:start + P], want), start
+    # the forward step and the second-order blocks on the same batch (their own index arithmetic)
+    xn = ac.state_update(Xb, Ub, 0.01)
+    assert torch.equal(xn[:, -P:], ac.state_update(Xs, Us, 0.01))
+    del out, xn
+    torch.cuda.empty_cache()
+    m = 5_200_000  # 441 x 5.2 M = 2.29e9 elements (9.2 GB)
+    lam = torch.ones((13, P), device=gpu)
+    Hb = ac.step_hess(Xb[:, :m].contiguous(), Ub[:, :m].contiguous(), 0.01, lam.repeat(1, m // P + 1)[:, :m].contiguous())
+    assert Hb.numel() > 2 ** 31
+    Hs = ac.step_hess(Xs, Us, 0.01, lam)
+    last = (m // P - 1) * P
+    assert torch.equal(Hb[..., last:last + P], Hs) and torch.equal(Hb[..., :P], Hs)
