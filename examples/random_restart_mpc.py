@@ -67,6 +67,8 @@ def main():
     x0 = torch.from_numpy(np.repeat(TRIM_STATE[:, None], B, axis=1).astype(np.float32)).to(dev)
     U0 = torch.from_numpy(np.ascontiguousarray(U_all[:, :, lo:hi])).to(dev)
 
+    # untimed warm-up on the real shapes: device workspaces (several GB at this size) are allocated on first use
+    solver.solve(x0, U0, iters=1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
