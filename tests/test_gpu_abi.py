@@ -154,3 +154,52 @@ def test_status_codes_of_the_widened_entry_points(gpu):
     assert lib.ac_ilqr_backward_newton_f32(h, C.byref(cost), nul, nul, nul, p(Hz), p(X), p(U), p(A), p(Bm), B, 0, p(K), p(kff), p(dV), st) == -1
     assert lib.ac_ilqr_cost_node_f32(h, C.byref(cost), p(X), p(X), p(X), 0, p(X), p(U), B, H, p(J), st) == -1  # Bn must be > 0
     torch.cuda.synchronize()
+
+
+def test_plain_c_program_against_the_python_host_path(gpu, tmp_path):
+    """examples/abi_demo.c drives the library from C with hipMalloc'd buffers (no Python, no torch types in the
+    signatures); its results must be what the Python host layer gets for the same inputs."""
+    import json
+    import os
+    import shutil
+    import subprocess
+
+    import torch
+
+    from aircraft_amd import Aircraft, AircraftConfiguration, AircraftOpts
+    from tests.helpers import ROOT
+
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no C toolchain / HIP headers on this box")
+    exe = str(tmp_path / "abi_demo")
+    lib_dir = os.path.join(ROOT, "aircraft_amd")
+    subprocess.run(["gcc", "-O2", os.path.join(ROOT, "examples", "abi_demo.c"), "-I" + os.path.join(ROOT, "include"),
+                    "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L" + lib_dir, "-laircraft_hip", "-L/opt/rocm/lib",
+                    "-lamdhip64", "-lm", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.strip().splitlines()[-1]
+    res = json.loads(out)
+    assert res["arch"].startswith("gfx950") and res["n"] == 1000
+    # the same problem through the Python host layer
+    N, H = 1000, 20
+    i = np.arange(N, dtype=np.float32); t = i / np.float32(N)
+    phi = np.float32(0.2) * np.sin(np.float32(7.0) * t); th = np.float32(0.05) * np.cos(np.float32(5.0) * t)
+    X = np.zeros((13, N), dtype=np.float32)
+    X[0] = 10 * t; X[1] = -5 * t; X[2] = -200; X[3] = 40 + 20 * t; X[4] = 1 - 2 * t; X[5] = 0.5
+    q = np.stack([0.5 * phi, 0.5 * th, 0.1 * t, np.ones(N, dtype=np.float32)]).astype(np.float32)
+    X[6:10] = q / np.sqrt((q * q).sum(axis=0, dtype=np.float32))
+    X[10] = 0.1 * phi; X[11] = 0.05; X[12] = -0.02 * t
+    U = np.zeros((7, N), dtype=np.float32)
+    U[0] = 2 * np.sin(np.float32(3.0) * t); U[1] = -1 + t; U[2] = 0.5 * t
+    cfg = AircraftConfiguration({"mass": 3.3, "reference_area": 0.238, "span": 1.75, "chord": 0.1375, "Ixx": 0.155,
+                                 "Iyy": 0.16, "Izz": 0.3, "Ixz": 0.01, "aero_centre_offset": [0.0, 0.0, 0.0]})
+    ac = Aircraft(AircraftOpts(coeff_model_type="default", aircraft_config=cfg, physical_integration_substeps=1))
+    ac.normalise = True
+    Xd, Ud = torch.from_numpy(X).to(gpu), torch.from_numpy(U).to(gpu)
+    Xn, A, Bm, c = ac.step_sens(Xd, Ud, 0.01)
+    traj = ac.rollout(Xd, Ud[None].expand(H, -1, -1).contiguous(), 0.01)
+    fro = lambda a: float(np.sqrt((a.cpu().numpy().astype(np.float64) ** 2).sum()))  # noqa: E731
+    # sinf/cosf of libm vs numpy differ in the last bit of a few inputs: compare to 1e-5, not bit for bit
+    assert np.allclose(res["x_next_unit0"], Xn[:, 0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    for key, val in (("frob_xn", fro(Xn)), ("frob_A", fro(A)), ("frob_B", fro(Bm)), ("frob_c", fro(c)),
+                     ("frob_rollout_end", fro(traj[-1]))):
+        assert abs(res[key] - val) <= 1e-5 * abs(val), key
