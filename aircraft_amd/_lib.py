@@ -68,6 +68,7 @@ PROTOTYPES = {
     "ac_shoot_step_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, C.c_long, _VP, _VP]),
     "ac_shoot_sens_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP, _VP]),
     "ac_step_hess_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _VP, C.c_long, _VP, _VP]),
+    "ac_reserve_hess_workspace": (C.c_int, [_VP, C.c_long]),
     "ac_shoot_hess_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
     "ac_aero_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, _VP, _VP]),
     "ac_traj_cost_f32": (C.c_int, [_VP, _VP, C.c_long, C.c_long, _FP, C.c_float, C.c_float, _VP, _VP]),

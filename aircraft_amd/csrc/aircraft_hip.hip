@@ -552,13 +552,10 @@ static int hess_impl(ac_handle* h, const float* X, const float* U, float dt, con
     if (h->dp.p.model_kind == AC_MODEL_NN) {
         // stage tensors (y, J, T at the four RK4 stage points) into the handle's workspace, then the same second-order
         // kernel with the tensor provider.  The workspace grows on demand: the first call of a given size allocates.
-        const size_t need = (size_t)n * kStageFloats;
-        if (need > h->hess_ws_floats) {
+        if ((size_t)n * kStageFloats > h->hess_ws_floats) {
             AC_HIP(hipStreamSynchronize(st));
-            if (h->d_hess_ws) (void)hipFree(h->d_hess_ws);
-            h->d_hess_ws = nullptr; h->hess_ws_floats = 0;
-            AC_HIP(hipMalloc((void**)&h->d_hess_ws, need * sizeof(float)));
-            h->hess_ws_floats = need;
+            rc = ac_reserve_hess_workspace(h, n);
+            if (rc != AC_OK) return rc;
         }
         const int grid_t = (int)((n + 63) / 64);
         const int lds = h->plan.lds_total;
@@ -585,6 +582,17 @@ static int hess_impl(ac_handle* h, const float* X, const float* U, float dt, con
     }
     note_launch(h, "k_step_hess", grid, kBlock, 0);
     AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_reserve_hess_workspace(ac_handle* h, long n) {
+    if (!h || n < 0) return AC_ERR_BAD_ARG;
+    const size_t need = (size_t)n * kStageFloats;
+    if (need <= h->hess_ws_floats) return AC_OK;
+    if (h->d_hess_ws) (void)hipFree(h->d_hess_ws);
+    h->d_hess_ws = nullptr; h->hess_ws_floats = 0;
+    AC_HIP(hipMalloc((void**)&h->d_hess_ws, need * sizeof(float)));
+    h->hess_ws_floats = need;
     return AC_OK;
 }
 

@@ -137,6 +137,9 @@ int ac_shoot_sens_f32(ac_handle* h, const float* X, const float* U, float dt, co
  * lambda [H][13][B] in place and writes Hout [H][21][21][B]. */
 int ac_step_hess_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit,
                      const float* lambda, long n, float* Hout, void* stream);
+/* Size the MLP path's workspace for n units ahead of time (e.g. before capturing a hipGraph); a no-op for the other
+ * models' needs and when it is already large enough. */
+int ac_reserve_hess_workspace(ac_handle* h, long n);
 int ac_shoot_hess_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit,
                       const float* lambda, long B, long H, float* Hout, void* stream);
 

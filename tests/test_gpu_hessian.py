@@ -60,7 +60,10 @@ def test_hessian_mlp_surrogate(gpu, hidden, normalise, use_mfma):
     assert np.abs(Hm - Hm.transpose(1, 0, 2)).max() <= 2e-5 * np.abs(Hm).max()
     for z in (0, 1, 2, 16, 17, 18):
         assert not Hm[z].any() and not Hm[:, z].any()
-    # a second, larger call re-uses / grows the handle's workspace
+    # the workspace can be sized ahead of time (hipGraph capture); a later, larger call re-uses / grows it
+    from aircraft_amd import _lib
+    assert _lib.load().ac_reserve_hess_workspace(ac._handle, 300) == 0
+    assert _lib.load().ac_reserve_hess_workspace(ac._handle, -1) == -1
     X2, U2, lam2 = units(300, seed=42)
     H2 = ac.step_hess(dev(X2, gpu), dev(U2, gpu), 0.01, dev(lam2, gpu)).cpu().numpy().astype(np.float64)
     assert rel_block(H2[:, :, :40], oracle_step_hessian(orc, X2[:, :40], U2[:, :40], 0.01, lam2[:, :40])) < 5e-4
