@@ -163,21 +163,27 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const No
         }
         if (j < 7 && rb == 0) squ[j] = C.r[j] * nd[273 + j];
         ilqr_sync();
-        // VA = V A, VB = V B
-        if (j < 13) {
-            for (int i = rb; i < 13; i += 4) {
-                float s = 0.f;
+        // This lane's columns of A_k and B_k stay in registers for the node (read once from the ring slot).
+        float acol[13], bcol[13];
 #pragma unroll
-                for (int m = 0; m < 13; ++m) s = fmaf(sV[i * 13 + m], sA[m * 13 + j], s);
-                sVA[i * 13 + j] = s;
-            }
+        for (int m = 0; m < 13; ++m) {
+            acol[m] = (j < 13) ? sA[m * 13 + j] : 0.f;
+            bcol[m] = (j < 7) ? sB[m * 7 + j] : 0.f;
         }
-        if (j < 7) {
-            for (int i = rb; i < 13; i += 4) {
-                float s = 0.f;
+        // VA = V A, VB = V B: one read of row i of V serves both products
 #pragma unroll
-                for (int m = 0; m < 13; ++m) s = fmaf(sV[i * 13 + m], sB[m * 7 + j], s);
-                sVB[i * 7 + j] = s;
+        for (int n = 0; n < 4; ++n) {
+            const int i = rb + 4 * n;
+            if (i < 13) {
+                float sa = 0.f, sb = 0.f;
+#pragma unroll
+                for (int m = 0; m < 13; ++m) {
+                    const float v = sV[i * 13 + m];
+                    sa = fmaf(v, acol[m], sa);
+                    sb = fmaf(v, bcol[m], sb);
+                }
+                if (j < 13) sVA[i * 13 + j] = sa;
+                if (j < 7) sVB[i * 7 + j] = sb;
             }
         }
         ilqr_sync();
@@ -185,64 +191,89 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const No
         float qxx[4] = {0.f, 0.f, 0.f, 0.f};
         float qx = 0.f, qu = 0.f;
         const float* hz = nd + 320;  // [21][21] (NEWTON only)
-        if (j < 13) {
-            qx = sqx[j];
+        {
+            float vacol[13], vbcol[13], vxs[13];  // column j of VA / VB, and V_x
 #pragma unroll
-            for (int m = 0; m < 13; ++m) qx = fmaf(sA[m * 13 + j], svx[m], qx);
-            for (int i = rb, n = 0; i < 13; i += 4, ++n) {
-                float s = (i == j) ? qjj : 0.f;
-                if constexpr (NEWTON) s += hz[i * 21 + j];
-#pragma unroll
-                for (int m = 0; m < 13; ++m) s = fmaf(sA[m * 13 + i], sVA[m * 13 + j], s);
-                qxx[n] = s;
+            for (int m = 0; m < 13; ++m) {
+                vacol[m] = (j < 13) ? sVA[m * 13 + j] : 0.f;
+                vbcol[m] = (j < 7) ? sVB[m * 7 + j] : 0.f;
+                vxs[m] = svx[m];
             }
-            for (int i = rb; i < 7; i += 4) {
-                float s = NEWTON ? hz[(13 + i) * 21 + j] : 0.f;
+            qx = (j < 13) ? sqx[j] : 0.f;
+            qu = (j < 7) ? squ[j] : 0.f;
 #pragma unroll
-                for (int m = 0; m < 13; ++m) s = fmaf(sB[m * 7 + i], sVA[m * 13 + j], s);
-                sQux[i * 13 + j] = s;
+            for (int m = 0; m < 13; ++m) { qx = fmaf(acol[m], vxs[m], qx); qu = fmaf(bcol[m], vxs[m], qu); }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int i = rb + 4 * n;
+                if (i < 13 && j < 13) {
+                    float s = (i == j) ? qjj : 0.f;
+                    if constexpr (NEWTON) s += hz[i * 21 + j];
+#pragma unroll
+                    for (int m = 0; m < 13; ++m) s = fmaf(sA[m * 13 + i], vacol[m], s);
+                    qxx[n] = s;
+                }
             }
-        }
-        if (j < 7) {
-            qu = squ[j];
 #pragma unroll
-            for (int m = 0; m < 13; ++m) qu = fmaf(sB[m * 7 + j], svx[m], qu);
-            for (int i = rb; i < 7; i += 4) {
-                float s = (i == j) ? C.r[j] + C.reg : 0.f;
-                if constexpr (NEWTON) s += hz[(13 + i) * 21 + 13 + j];
+            for (int n = 0; n < 2; ++n) {
+                const int i = rb + 4 * n;
+                if (i < 7) {  // column i of B_k serves row i of Qux and of Quu
+                    float sx = NEWTON ? ((j < 13) ? hz[(13 + i) * 21 + j] : 0.f) : 0.f;
+                    float su = (i == j) ? C.r[j < 7 ? j : 0] + C.reg : 0.f;
+                    if constexpr (NEWTON) su += (j < 7) ? hz[(13 + i) * 21 + 13 + j] : 0.f;
 #pragma unroll
-                for (int m = 0; m < 13; ++m) s = fmaf(sB[m * 7 + i], sVB[m * 7 + j], s);
-                sQuu[i * 7 + j] = s;
+                    for (int m = 0; m < 13; ++m) {
+                        const float bi = sB[m * 7 + i];
+                        sx = fmaf(bi, vacol[m], sx);
+                        su = fmaf(bi, vbcol[m], su);
+                    }
+                    if (j < 13) sQux[i * 13 + j] = sx;
+                    if (j < 7) sQuu[i * 7 + j] = su;
+                }
             }
         }
         ilqr_sync();  // Qux, Quu complete; sqx / squ / svx fully read
         if (j < 7 && rb == 0) squ[j] = qu;  // now holds Qu
         ilqr_sync();
-        // Cholesky Quu = L L' (every lane, in registers), then K(:, j) = -Quu^-1 Qux(:, j), kff = -Quu^-1 Qu
-        float L[7][7];
+        // Cholesky Quu = L L' (every lane, in registers; reciprocal diagonal via rsq, no divisions), then
+        // K(:, j) = -Quu^-1 Qux(:, j), kff = -Quu^-1 Qu
+        float Qs[7][7];  // symmetrised Quu
 #pragma unroll
         for (int i = 0; i < 7; ++i)
 #pragma unroll
-            for (int m = 0; m <= i; ++m) {
-                float s = 0.5f * (sQuu[i * 7 + m] + sQuu[m * 7 + i]);
+            for (int m = 0; m <= i; ++m) { Qs[i][m] = 0.5f * (sQuu[i * 7 + m] + sQuu[m * 7 + i]); Qs[m][i] = Qs[i][m]; }
+        float L[7][7], rinv[7];
 #pragma unroll
-                for (int p = 0; p < m; ++p) s -= L[i][p] * L[m][p];
-                L[i][m] = (i == m) ? sqrtf(fmaxf(s, 1e-12f)) : s / L[m][m];
+        for (int m = 0; m < 7; ++m) {
+            float d = Qs[m][m];
+#pragma unroll
+            for (int p = 0; p < m; ++p) d = fmaf(-L[m][p], L[m][p], d);
+            d = fmaxf(d, 1e-12f);
+            rinv[m] = __builtin_amdgcn_rsqf(d);
+            rinv[m] = rinv[m] * fmaf(-0.5f * d * rinv[m], rinv[m], 1.5f);  // one Newton step: full fp32 accuracy
+            L[m][m] = d * rinv[m];
+#pragma unroll
+            for (int i = m + 1; i < 7; ++i) {
+                float s = Qs[i][m];
+#pragma unroll
+                for (int p = 0; p < m; ++p) s = fmaf(-L[i][p], L[m][p], s);
+                L[i][m] = s * rinv[m];
             }
+        }
         auto solve = [&](float rhs[7]) {  // in place: rhs <- Quu^-1 rhs
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
                 float s = rhs[i];
 #pragma unroll
-                for (int p = 0; p < i; ++p) s -= L[i][p] * rhs[p];
-                rhs[i] = s / L[i][i];
+                for (int p = 0; p < i; ++p) s = fmaf(-L[i][p], rhs[p], s);
+                rhs[i] = s * rinv[i];
             }
 #pragma unroll
             for (int i = 6; i >= 0; --i) {
                 float s = rhs[i];
 #pragma unroll
-                for (int p = i + 1; p < 7; ++p) s -= L[p][i] * rhs[p];
-                rhs[i] = s / L[i][i];
+                for (int p = i + 1; p < 7; ++p) s = fmaf(-L[p][i], rhs[p], s);
+                rhs[i] = s * rinv[i];
             }
         };
         float kf[7], quv[7];
@@ -268,7 +299,7 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const No
         for (int i = 0; i < 7; ++i) {
             float t = 0.f;
 #pragma unroll
-            for (int m = 0; m < 7; ++m) t = fmaf(0.5f * (sQuu[i * 7 + m] + sQuu[m * 7 + i]), kf[m], t);
+            for (int m = 0; m < 7; ++m) t = fmaf(Qs[i][m], kf[m], t);
             quukf[i] = t;
         }
         if (threadIdx.x == 0) {
@@ -283,37 +314,50 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const No
         // V_x(j) = Qx + K' Quu kff + K' Qu + Qux' kff ;  V_xx(i, j) = Qxx + K' Quu K + K' Qux + Qux' K
         float vx = 0.f, vrow[4] = {0.f, 0.f, 0.f, 0.f};
         if (j < 13) {
-            float quuk[7];  // Quu K(:, j)
+            float w[7], quxj[7];  // w = Quu K(:, j) + Qux(:, j)
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
-                float s = 0.f;
+                float sq = 0.f;
 #pragma unroll
-                for (int m = 0; m < 7; ++m) s = fmaf(0.5f * (sQuu[i * 7 + m] + sQuu[m * 7 + i]), kcol[m], s);
-                quuk[i] = s;
+                for (int m = 0; m < 7; ++m) sq = fmaf(Qs[i][m], kcol[m], sq);
+                quxj[i] = sQux[i * 13 + j];
+                w[i] = sq + quxj[i];
             }
             vx = qx;
 #pragma unroll
-            for (int i = 0; i < 7; ++i) vx += kcol[i] * (quukf[i] + quv[i]) + sQux[i * 13 + j] * kf[i];
-            for (int i = rb, n = 0; i < 13; i += 4, ++n) {
-                float s = qxx[n];
+            for (int i = 0; i < 7; ++i) vx += kcol[i] * (quukf[i] + quv[i]) + quxj[i] * kf[i];
 #pragma unroll
-                for (int m = 0; m < 7; ++m) s += sK[m * 13 + i] * (quuk[m] + sQux[m * 13 + j]) + sQux[m * 13 + i] * kcol[m];
-                vrow[n] = s;
+            for (int n = 0; n < 4; ++n) {
+                const int i = rb + 4 * n;
+                if (i < 13) {
+                    float sv = qxx[n];
+#pragma unroll
+                    for (int m = 0; m < 7; ++m) sv += sK[m * 13 + i] * w[m] + sQux[m * 13 + i] * kcol[m];
+                    vrow[n] = sv;
+                }
             }
         }
         ilqr_sync();  // every lane has read the old V / Qux before they are overwritten
         if (j < 13) {
             if (rb == 0) svx[j] = vx;
-            for (int i = rb, n = 0; i < 13; i += 4, ++n) sV[i * 13 + j] = vrow[n];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (rb + 4 * n < 13) sV[(rb + 4 * n) * 13 + j] = vrow[n];
         }
         ilqr_sync();
         // symmetrise V: entry (i, j) <- mean with (j, i); both read before either is written
         float sym[4] = {0.f, 0.f, 0.f, 0.f};
-        if (j < 13)
-            for (int i = rb, n = 0; i < 13; i += 4, ++n) sym[n] = 0.5f * (sV[i * 13 + j] + sV[j * 13 + i]);
+        if (j < 13) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (rb + 4 * n < 13) sym[n] = 0.5f * (vrow[n] + sV[j * 13 + rb + 4 * n]);
+        }
         ilqr_sync();
-        if (j < 13)
-            for (int i = rb, n = 0; i < 13; i += 4, ++n) sV[i * 13 + j] = sym[n];
+        if (j < 13) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (rb + 4 * n < 13) sV[(rb + 4 * n) * 13 + j] = sym[n];
+        }
         ilqr_sync();
         if (k - R::kDepth >= 0) issue(k - R::kDepth, slot);  // every read of this slot has retired (lgkmcnt(0) above)
     }
