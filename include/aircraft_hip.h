@@ -133,8 +133,10 @@ int ac_shoot_sens_f32(ac_handle* h, const float* X, const float* U, float dt, co
  * Exact second-order forward mode of the same fp32 arithmetic as ac_step_f32.  Rows/columns of p (0-2) and of controls
  * without effect are zero.  All force models (the MLP surrogate evaluates its second-derivative tensor with the MFMA
  * engine into a handle-owned workspace of n*504 floats that grows on demand — the first call of a size allocates, so
- * capture a hipGraph only after one warm-up call); substeps == 1 only, AC_ERR_UNSUPPORTED otherwise.  ac_shoot_hess_f32 reads rollout-shaped X [H(+1)][13][B], U [H][7][B],
- * lambda [H][13][B] in place and writes Hout [H][21][21][B]. */
+ * capture a hipGraph only after one warm-up call or ac_reserve_hess_workspace); substeps == 1 only,
+ * AC_ERR_UNSUPPORTED otherwise.  Hout is zero-filled by the call (hipMemsetAsync on `stream`) before the active block is
+ * written.  ac_shoot_hess_f32 reads rollout-shaped X [H(+1)][13][B], U [H][7][B], lambda [H][13][B] in place and writes
+ * Hout [H][21][21][B]. */
 int ac_step_hess_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit,
                      const float* lambda, long n, float* Hout, void* stream);
 /* Size the MLP path's workspace for n units ahead of time (e.g. before capturing a hipGraph); a no-op for the other
