@@ -45,9 +45,52 @@ def parse():
     ap.add_argument("--horizon", type=int, default=50)
     ap.add_argument("--hidden", type=str, default="128,128,128,128")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the second-order / closed-loop figures reported alongside")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-mfma", action="store_true", help="VALU matmul path (validation baseline)")
     return ap.parse_args()
+
+
+def extras(ac, ms, X, U, dev):
+    """Reported alongside the headline, N=1 only, a few seconds: the second-order blocks of the same units and the
+    receding-horizon closed loop of BASELINE configs[4] (B=1024, H=50, hipGraph replay).  Never fails the bench."""
+    import torch
+
+    out = {}
+    try:
+        H, _, B = U.shape
+        Lam = torch.randn((H, 13, B), device=dev)
+        Hz = torch.empty((H, 21, 21, B), device=dev)
+        ms.hessian(X, U, Lam, out=Hz); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            ms.hessian(X, U, Lam, out=Hz)
+        e1.record(); torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / 3
+        out["second_order_blocks_units_per_s"] = B * H / t * 1e3
+        out["second_order_blocks_ms"] = t
+        del Hz, Lam
+    except Exception as e:  # noqa: BLE001
+        out["second_order_blocks_error"] = repr(e)
+    try:
+        from aircraft_amd.control import ILQR, QuadraticCost, RecedingHorizon
+
+        Bc, Hc = 1024, 50
+        cost = QuadraticCost.goal((30.0, 0.5), w_goal=1.0, height=-200.0, w_lateral_speed=0.5, r=0.5, reg=1.0)
+        il = ILQR(system=ac, dt=ms.dt, num_nodes=Hc, cost=cost, alphas=(1.0, 0.5, 0.1))
+        x0 = X[0, :, :Bc].contiguous()
+        U0 = U[:Hc, :, :Bc].contiguous()
+        loop = RecedingHorizon(il, overlap=30, iterations=2).allocate(x0, U0).capture()
+        loop.run(3); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); loop.run(300); e1.record(); torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / 300
+        out["closed_loop_ms_per_solve"] = t
+        out["closed_loop"] = "B=1024 x H=50, 2 iLQR iterations per solve, overlap 30, one captured cycle replayed 300 times"
+    except Exception as e:  # noqa: BLE001
+        out["closed_loop_error"] = repr(e)
+    return out
 
 
 def cpu_baseline(ac, X, U, dt, seconds):
@@ -214,6 +257,8 @@ def main():
             "forward_tflops": (4 * F_mlp + 1500) * B * H / (fwd_ms * 1e-3) / 1e12,
             "rollout_steps_per_s_per_gpu": B * H / roll_ms * 1e3, "rollout_ms": roll_ms,
             "note": "same units, x+ only: ac_shoot_step_f32 (all nodes independent) and ac_rollout_f32 (sequential in k)"}
+        if world == 1 and not args.no_extras:
+            res["alongside"].update(extras(ac, ms, X, U, dev))
         if not args.no_cpu_baseline and world == 1:
             Xs = Xh[:H].transpose(1, 0, 2).reshape(13, H * B)
             Us = Uh.transpose(1, 0, 2).reshape(7, H * B)
