@@ -91,10 +91,17 @@ __global__ __launch_bounds__(kBlock) void k_track_progress(const TrackDev T, con
     float s = s0[b];
     S[b] = s;
     const bool model = node_q != nullptr;
+    // the recursion in s is the only dependence between nodes: the next node's position / velocity are loaded while this
+    // node's track terms are computed
+    float pn[3] = {X[b], X[B + b], X[2 * B + b]}, vn[3] = {X[3 * B + b], X[4 * B + b], X[5 * B + b]};
     for (long k = 0; k < H; ++k) {
-        const float* xk = X + k * 13 * B + b;
-        const float p[3] = {xk[0], xk[B], xk[2 * B]};
-        const float v[3] = {xk[3 * B], xk[4 * B], xk[5 * B]};
+        const float p[3] = {pn[0], pn[1], pn[2]};
+        const float v[3] = {vn[0], vn[1], vn[2]};
+        {
+            const float* xn = X + (k + 1) * 13 * B + b;  // node k+1 <= H always exists
+            pn[0] = xn[0]; pn[1] = xn[B]; pn[2] = xn[2 * B];
+            vn[0] = xn[3 * B]; vn[1] = xn[4 * B]; vn[2] = xn[5 * B];
+        }
         const TrackTerms t = track_terms(T, s, p, v, mode != 0);
         if (sdot) sdot[k * B + b] = t.s_dot;
         if (err2) err2[k * B + b] = t.err2;

@@ -73,6 +73,13 @@ def main():
     X0[3] += rng.uniform(-3, 3, B)
     x0 = torch.as_tensor(X0, dtype=torch.float32, device=dev)
     U0 = torch.zeros((N, 7, B), device=dev)
+    # one untimed dry pass of everything the timed loop touches — including the torch reductions used for the stop test
+    # and the statistics, whose code objects a fresh process loads from disk on first use (~65 ms on a cold box)
+    mhtt.set_progress(np.zeros(B))
+    dry = RecedingHorizon(mhtt, overlap=args.overlap, iterations=args.iters).allocate(x0, U0)
+    dry.run(2)
+    _ = float(mhtt.s0.median()), mhtt.track_eval(mhtt.s0), (dry.x0[:3] - dry.x0[:3]).norm(dim=0), dry.executed.clone()
+    torch.cuda.synchronize()
     mhtt.set_progress(np.zeros(B))
     loop = RecedingHorizon(mhtt, overlap=args.overlap, iterations=args.iters).allocate(x0, U0)
     if not args.eager:
