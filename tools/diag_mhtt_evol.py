@@ -1,12 +1,16 @@
+#!/usr/bin/env python3
+"""Cycle time of the MHTT receding-horizon loop over the lifetime of a fresh process (eager and hipGraph alternating):
+shows what is steady state and what is first-use cost."""
 import os, sys, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/examples")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "examples"))
 import numpy as np, torch
 from mhtt_track import s_bend
 from aircraft_amd import Aircraft, AircraftConfiguration, AircraftOpts
 from aircraft_amd.control import MHTT, RecedingHorizon, Track
 from aircraft_amd.synthetic import GLIDER, TRIM_STATE
 dev = torch.device("cuda", 0)
-ac = Aircraft(AircraftOpts(coeff_model_type="poly", coeff_model_path="/root/repo/tests/golden/poly_coef.npz",
+ac = Aircraft(AircraftOpts(coeff_model_type="poly", coeff_model_path=os.path.join(ROOT, "tests", "golden", "poly_coef.npz"),
                            aircraft_config=AircraftConfiguration(dict(GLIDER)), physical_integration_substeps=3))
 mh = MHTT(system=ac, track=Track(s_bend()), dt=0.03, num_nodes=100)
 B = 1024
