@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 OBJ = os.path.join(_HERE, "csrc", "_obj")
 OUT = os.path.join(_HERE, "libaircraft_hip.so")
 HEADERS = glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(_HERE, "..", "include", "aircraft_hip.h")]
-CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-pass-failed"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-pass-failed", "-ffp-contract=on"]
 
 
 def sources():

@@ -68,6 +68,64 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_step_sens(const DevParams P, c
 #endif
 }
 
+// The sensitivity step for a REMAINDER of units that would leave the last round of the grid half empty: a wave's time
+// is set by its slab count, not by its live columns, so a unit group (16 units) is given to a PAIR of waves — one
+// carries the value slab and tangents 0-2, the other the value slab and tangents 3-4 — and a workgroup holds two
+// groups (32 units).  Both waves run the whole dual RK4 arithmetic on identical inputs (so the pair's results are
+// bit-identical to k_nn_step_sens'); they exchange their Jacobian columns through LDS after every network evaluation;
+// the first wave of the pair stores.  Twice the workgroups, each ~0.73 of the time of a full one.
+template <class Engine, int TOFF>
+AC_DI void sens_pair_body(const DevParams& P, const MlpPlan& plan, const float* __restrict__ blob, char* smem,
+                          float* xch, bool store, const float* __restrict__ X, const float* __restrict__ U, float dt,
+                          const float* __restrict__ dt_per_unit, long n, long blk, long unit0, int pair,
+                          float* __restrict__ Xn, float* __restrict__ A, float* __restrict__ Bm,
+                          float* __restrict__ c) {
+    Engine eng(plan, blob, smem);
+    eng.load_weights();
+    const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4;
+    const long raw = unit0 + ((long)blockIdx.x * 2 + pair) * 16 + col;
+    const bool live = raw < n;
+    const long unit = live ? raw : n - 1;
+    const UnitAddr ua(unit, blk);
+    float xv[13], uv[7];
+    load_rows<13>(X, ua, xv);
+    load_rows<7>(U, ua, uv);
+    const float hv = dt_per_unit ? dt_per_unit[unit] : dt;
+    Dual<4> x[13];
+    MlpPairCoeffs<Engine, TOFF> coeffs(eng, xch);
+    const bool out = live && store;
+    sens_update<4>(P, coeffs, g, col, ua, xv, uv, hv, x, A, Bm, c, out);
+    eng.drain();
+    if (out) {
+        const UnitAddr uo = ua.late();
+        if (g == 0) {
+            float* p = Xn + uo.off(13);
+#pragma unroll
+            for (int i = 0; i < 13; ++i) p[(long)i * blk] = x[i].v;
+        }
+        SensIO::store(g, uo, x, A, Bm, c, true);
+    }
+}
+
+template <int WT>
+__global__ __launch_bounds__(kBlock, 1) void k_nn_step_sens_pair(const DevParams P, const MlpPlan plan,
+                                                                 const float* __restrict__ blob,
+                                                                 const float* __restrict__ X, const float* __restrict__ U,
+                                                                 float dt, const float* __restrict__ dt_per_unit, long n,
+                                                                 long blk, float* __restrict__ Xn, float* __restrict__ A,
+                                                                 float* __restrict__ Bm, float* __restrict__ c,
+                                                                 long unit0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, role = wave & 1, pair = wave >> 1;
+    float* xch = reinterpret_cast<float*>(smem + plan.lds_total) + pair * (2 * 16 * 30);
+    if (role == 0)
+        sens_pair_body<MlpEngine<4, WT, true, true, false, 0>, 0>(P, plan, blob, smem, xch, true, X, U, dt, dt_per_unit, n, blk,
+                                                                   unit0, pair, Xn, A, Bm, c);
+    else
+        sens_pair_body<MlpEngine<3, WT, true, true, false, 3>, 3>(P, plan, blob, smem, xch, false, X, U, dt, dt_per_unit, n,
+                                                                   blk, unit0, pair, Xn, A, Bm, c);
+}
+
 template <int WT, bool USE_MFMA, int OP>
 __global__ __launch_bounds__(kBlock, 1) void k_nn_fwd(const DevParams P, const MlpPlan plan,
                                                       const float* __restrict__ blob, const float* __restrict__ X,

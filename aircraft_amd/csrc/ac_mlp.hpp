@@ -85,9 +85,12 @@ AC_DI void lds_dma_copy(const float* __restrict__ gsrc, char* lds_dst, int bytes
 // or NSLAB = 4 (64 units, lane = unit; slab s = units 16 s .. 16 s + 15).  WT: register tiles per slab = width / 16.
 // SECOND (second-order mode, NSLAB == 6): slabs = value, d/dz_p, d/dz_q, d2/dz_p2, d2/dz_q2, d2/dz_p dz_q for one
 // input pair (p, q) set with set_pair(); used by the Hessian path (ac_hess_nn.hpp), never by the step kernels.
-template <int NSLAB, int WT, bool USE_MFMA, bool TANGENT = (NSLAB == 6), bool SECOND = false>
+// TOFF (tangent mode with fewer slabs): tangent slab s carries input TOFF + s - 1 — a wave pair splits the five
+// tangents as value + {0, 1, 2} and value + {3, 4} (k_nn_step_sens_pair).
+template <int NSLAB, int WT, bool USE_MFMA, bool TANGENT = (NSLAB == 6), bool SECOND = false, int TOFF = 0>
 struct MlpEngine {
-    static_assert(!TANGENT || NSLAB == 6, "tangent mode = value + 5 input tangents");
+    static_assert(!TANGENT || (NSLAB >= 2 && NSLAB <= 6 && TOFF + NSLAB - 1 <= 5), "tangent mode = value + a range of the 5 input tangents");
+    static constexpr int kTangents = TANGENT ? NSLAB - 1 : 0;
     static_assert(!SECOND || (NSLAB == 6 && !TANGENT), "second-order mode = value + 2 first-order + 3 second-order slabs");
     static constexpr bool kTangent = TANGENT;
     static constexpr bool kDeriv = TANGENT || SECOND;  // slabs > 0 are derivative slabs (no bias, chain-rule epilogue)
@@ -258,10 +261,10 @@ struct MlpEngine {
         }
         if constexpr (kTangent) {
 #pragma unroll
-            for (int j = 0; j < 5; ++j)
+            for (int j = 0; j < kTangents; ++j)
 #pragma unroll
                 for (int nt = 0; nt < WT; ++nt) {
-                    const f32x4 w = w0t[j * (WT * 4) + 4 * nt + g];
+                    const f32x4 w = w0t[(TOFF + j) * (WT * 4) + 4 * nt + g];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float h = a[0][nt][r];
@@ -331,7 +334,7 @@ struct MlpEngine {
                 a[0][0][r] = v;
                 if constexpr (kTangent) {
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) a[1 + j][0][r] = (row == j) ? 1.f : 0.f;
+                    for (int j = 0; j < kTangents; ++j) a[1 + j][0][r] = (row == TOFF + j) ? 1.f : 0.f;
                 }
                 if constexpr (SECOND) {
                     a[1][0][r] = (row == pair_p) ? 1.f : 0.f;
@@ -376,7 +379,7 @@ struct MlpEngine {
                 y[k] = __shfl(a[0][0][k & 3], src, 64);
                 if constexpr (kDeriv) {  // SECOND: J[k][0..4] = dy/dz_p, dy/dz_q, d2y/dz_p2, d2y/dz_q2, d2y/dz_p dz_q
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) J[k][j] = __shfl(a[1 + j][0][k & 3], src, 64);
+                    for (int j = 0; j < NSLAB - 1; ++j) J[k][j] = __shfl(a[1 + j][0][k & 3], src, 64);  // partial: local columns
                 }
             }
         }
@@ -664,6 +667,74 @@ template <class Engine> struct MlpCoeffs {
                           Dual<N> C[6]) const {
         (void)x;
         static_assert(Engine::kTangent, "dual coefficients need the tangent engine");
+        const Dual<N> in[5] = {a.qbar, a.alpha, a.beta, u[0], u[1]};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            C[k].v = fmaf(y[k], P.mlp_out_std[k], P.mlp_out_mean[k]);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) s = fmaf(J[k][j] * (P.mlp_out_std[k] / P.mlp_in_std[j]), in[j].d[i], s);
+                C[k].d[i] = s;
+            }
+        }
+        C[5] = C[5] + (-0.1f * 6.0f * kDeg) * u[2];
+    }
+};
+
+
+// Provider for a wave PAIR that splits the five input tangents (k_nn_step_sens_pair): this wave's engine delivers y and
+// the Jacobian columns TOFF .. TOFF + Engine::kTangents - 1; the pair completes J through a double-buffered LDS
+// exchange (one workgroup barrier per network evaluation; every wave of the workgroup runs the same sequence).
+template <class Engine, int TOFF> struct MlpPairCoeffs {
+    static constexpr int kModel = AC_MODEL_NN;
+    Engine& eng;
+    float* xch;  // [2 parities][16 units][30] floats of this pair
+    int parity;
+    float y[6];
+    float J[6][5];
+    AC_DI MlpPairCoeffs(Engine& e, float* exchange) : eng(e), xch(exchange), parity(0) {}
+
+    template <class T> AC_DI void prefetch(const DevParams& P, const T x[13], const float uv[7]) {
+        float xf[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) xf[i] = value_of(x[i]);
+        AeroPre<float> a;
+        aero_pre(P, xf, a);
+        const float in[5] = {a.qbar, a.alpha, a.beta, uv[0], uv[1]};
+        float z[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) z[j] = (in[j] - P.mlp_in_mean[j]) / P.mlp_in_std[j];
+        float Jl[6][5];
+        eng.forward(z, y, Jl);
+        float* buf = xch + parity * (16 * 30) + (eng.lane & 15) * 30;
+        if (eng.g == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int j = 0; j < Engine::kTangents; ++j) buf[k * 5 + TOFF + j] = Jl[k][j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) J[k][j] = buf[k * 5 + j];
+        parity ^= 1;
+    }
+
+    AC_DI void operator()(const DevParams& P, const AeroPre<float>& a, const float x[13], const float u[7],
+                          float C[6]) const {
+        (void)a; (void)x;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) C[k] = fmaf(y[k], P.mlp_out_std[k], P.mlp_out_mean[k]);
+        C[5] += (-0.1f * 6.0f * kDeg) * u[2];
+    }
+
+    template <int N>
+    AC_DI void operator()(const DevParams& P, const AeroPre<Dual<N>>& a, const Dual<N> x[13], const Dual<N> u[7],
+                          Dual<N> C[6]) const {
+        (void)x;
         const Dual<N> in[5] = {a.qbar, a.alpha, a.beta, u[0], u[1]};
 #pragma unroll
         for (int k = 0; k < 6; ++k) {

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -58,6 +59,7 @@ struct ac_handle {
     DevParams dp;
     int device;
     int num_cus;
+    bool no_pair;  // AIRCRAFT_HIP_NO_PAIR=1 (measurement aid): never route a remainder to k_nn_step_sens_pair
     bool has_linear, has_poly, has_mlp;
     MlpPlan plan;
     int wt;         // register tiles per slab the plan needs (2, 4 or 8)
@@ -176,6 +178,10 @@ int ac_create(const ac_params* params, ac_handle** out) {
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess) h->num_cus = cus;
+    }
+    {
+        const char* e = getenv("AIRCRAFT_HIP_NO_PAIR");
+        h->no_pair = e && e[0] == '1';
     }
     *out = h;
     return AC_OK;
@@ -503,18 +509,49 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
     if (rc != AC_OK) return rc;
     if (n == 0) return AC_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = (int)((n + 63) / 64);  // MLP: 16 units per wave, 4 waves per workgroup
     if (h->dp.p.model_kind == AC_MODEL_NN) {
-        bool launched = false;
-        AC_NN_CASE(2, true, (k_nn_step_sens<2, true>), grid, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c)
-        AC_NN_CASE(4, true, (k_nn_step_sens<4, true>), grid, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c)
-        AC_NN_CASE(8, true, (k_nn_step_sens<8, true>), grid, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c)
-        AC_NN_CASE(2, false, (k_nn_step_sens<2, false>), grid, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c)
-        AC_NN_CASE(4, false, (k_nn_step_sens<4, false>), grid, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c)
-        AC_NN_CASE(8, false, (k_nn_step_sens<8, false>), grid, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c)
-        if (!launched) return AC_ERR_UNSUPPORTED;
-        note_launch(h, "k_nn_step_sens", grid, kBlock, h->plan.lds_total);
-        AC_HIP(hipGetLastError());
+        // MLP: 16 units per wave, 4 waves (64 units) per workgroup, one workgroup resident per CU — time goes in whole
+        // rounds over the CUs.  A remainder of at most half a round is given to k_nn_step_sens_pair (two waves per 16
+        // units, 32 units per workgroup, ~0.73 of a full workgroup's time) instead of paying a full round for it.
+        const long cus = h->num_cus > 0 ? h->num_cus : 256;
+        const long per_round = 64 * cus;
+        long n_main = n, n_pair = 0;
+        if (h->use_mfma && !h->no_pair) {
+            const long rem = n % per_round;
+            if (rem > 0 && rem <= 32 * cus) { n_main = n - rem; n_pair = rem; }
+        }
+        if (n_main > 0) {
+            const int grid = (int)((n_main + 63) / 64);
+            bool launched = false;
+            AC_NN_CASE(2, true, (k_nn_step_sens<2, true>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
+            AC_NN_CASE(4, true, (k_nn_step_sens<4, true>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
+            AC_NN_CASE(8, true, (k_nn_step_sens<8, true>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
+            AC_NN_CASE(2, false, (k_nn_step_sens<2, false>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
+            AC_NN_CASE(4, false, (k_nn_step_sens<4, false>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
+            AC_NN_CASE(8, false, (k_nn_step_sens<8, false>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
+            if (!launched) return AC_ERR_UNSUPPORTED;
+            note_launch(h, "k_nn_step_sens", grid, kBlock, h->plan.lds_total);
+            AC_HIP(hipGetLastError());
+        }
+        if (n_pair > 0) {
+            const int grid_p = (int)((n_pair + 31) / 32);
+            const int lds_p = h->plan.lds_total + 2 * 2 * 16 * 30 * (int)sizeof(float);  // + the pairs' Jacobian exchange
+            bool launched = false;
+#define AC_PAIR_CASE(WT_)                                                                                              \
+            if (h->wt == WT_) {                                                                                        \
+                auto kern = k_nn_step_sens_pair<WT_>;                                                                  \
+                int rc_ = set_lds_limit(kern, lds_p);                                                                  \
+                if (rc_ != AC_OK) return rc_;                                                                          \
+                hipLaunchKernelGGL(kern, grid_p, kBlock, lds_p, st, h->dp, h->plan, h->d_blob, X, U, dt, dt_per_unit, n, \
+                                   blk, Xn, A, Bm, c, n_main);                                                          \
+                launched = true;                                                                                       \
+            }
+            AC_PAIR_CASE(2) AC_PAIR_CASE(4) AC_PAIR_CASE(8)
+#undef AC_PAIR_CASE
+            if (!launched) return AC_ERR_UNSUPPORTED;
+            if (n_main == 0) note_launch(h, "k_nn_step_sens_pair", grid_p, kBlock, lds_p);
+            AC_HIP(hipGetLastError());
+        }
         return AC_OK;
     }
     // analytic: 4 N units per wave, N = directions per lane of the model (AnalyticSensN), 4 waves per workgroup
