@@ -250,6 +250,9 @@ def main():
                          "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
                          "algorithmic_bytes_per_launch": bytes_unit * B * H,
                          "kernel": name, "kernel_ms": kern_ms, "grid": grid, "block": block, "lds_bytes": lds,
+                         "kernel_note": "kernel_ms spans the whole step: k_nn_step_sens on the units that fill whole rounds of "
+                                        "64-unit workgroups over the CUs, then k_nn_step_sens_pair on a remainder of at most "
+                                        "half a round (grid/block/lds are the first kernel's)",
                          "flops_per_unit": flops_unit, "hbm_bytes_per_unit": bytes_unit,
                          "hbm_achieved_GBs": achieved_gbs, "hbm_frac": achieved_gbs / PEAK_HBM_GBS},
         }
