@@ -1,4 +1,8 @@
-import sys; sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""Bitwise comparison of k_nn_step_sens_pair (n < half a round) with k_nn_step_sens (same units in a whole-round batch):
+which outputs differ, where, by how much.  (With -ffp-contract=on: nothing.)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tests.helpers import make_aircraft, synthetic_units
 gpu = torch.device("cuda", 0)
