@@ -1,0 +1,14 @@
+import sys, traceback
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import torch
+from tests.test_gpu_fuzz import test_random_configuration as f
+gpu = torch.device("cuda", 0)
+bad = []
+for seed in range(12, 212):
+    try:
+        f(gpu, seed)
+    except Exception as e:
+        bad.append((seed, repr(e)[:300]))
+        print("FAIL", seed, repr(e)[:300], flush=True)
+    if seed % 25 == 0: print("done", seed, flush=True)
+print("failures:", len(bad), bad[:5])
