@@ -260,17 +260,24 @@ struct MlpEngine {
             for (int nt = 0; nt < WT; ++nt) epilogue_tile<WT>(sv, nt, o, act);
         }
         if constexpr (kTangent) {
+            // tile by tile: the W0 columns of all tangents are requested together (one LDS wait per tile, not one per
+            // read) and act'(h) is formed once per element
 #pragma unroll
-            for (int j = 0; j < kTangents; ++j)
+            for (int nt = 0; nt < WT; ++nt) {
+                f32x4 w[kTangents];
 #pragma unroll
-                for (int nt = 0; nt < WT; ++nt) {
-                    const f32x4 w = w0t[(TOFF + j) * (WT * 4) + 4 * nt + g];
+                for (int j = 0; j < kTangents; ++j) w[j] = w0t[(TOFF + j) * (WT * 4) + 4 * nt + g];
+                float sp[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float h = a[0][nt][r];
-                        a[1 + j][nt][r] = act ? w[r] * fmaf(-h, h, 1.0f) : w[r];
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const float h = a[0][nt][r];
+                    sp[r] = act ? fmaf(-h, h, 1.0f) : 1.0f;
                 }
+#pragma unroll
+                for (int j = 0; j < kTangents; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[1 + j][nt][r] = w[j][r] * sp[r];
+            }
         }
         if constexpr (SECOND) {
             // z = W0 in + b is linear in the inputs: h_a = s' W0[:, a], h_ab = s'' W0[:, a] W0[:, b] = -2 h h_a W0[:, b]
