@@ -72,11 +72,15 @@ AC_DI float act_tanh(float x) {
 // global_load_lds_dwordx4 wave-instruction (LDS destination = piece base + 16 * lane, all lanes active).
 AC_DI void lds_dma_copy(const float* __restrict__ gsrc, char* lds_dst, int bytes, int wave, int nwaves,
                         int lane) {
-    const int pieces = bytes >> 10;
-    for (int p = wave; p < pieces; p += nwaves) {
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)((const char*)gsrc + (p << 10) + lane * 16),
-            (__attribute__((address_space(3))) void*)(lds_dst + (p << 10)), 16, 0, 0);
+    // the piece loop is wave-uniform: run it on the scalar unit (uniform base + one VGPR offset per lane) instead of as an
+    // exec-masked vector loop with a 64-bit vector address and a readfirstlane for M0 per piece
+    const int pieces = __builtin_amdgcn_readfirstlane(bytes >> 10);
+    const int w0 = __builtin_amdgcn_readfirstlane(wave), step = __builtin_amdgcn_readfirstlane(nwaves);
+    const unsigned voff = (unsigned)lane * 16u;
+    for (int p = w0; p < pieces; p += step) {
+        const char* base = (const char*)gsrc + ((long)p << 10);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff),
+                                         (__attribute__((address_space(3))) void*)(lds_dst + (p << 10)), 16, 0, 0);
     }
 }
 
