@@ -35,6 +35,7 @@ struct MlpPlan {
     int ring_off[2];             // byte offsets of the two ring slots
     int n_streamed;              // number of streamed layers per forward pass
     int first_streamed;          // index of the first streamed layer (-1 if none)
+    int streamed[AC_MAX_LAYERS]; // layer index of the i-th streamed layer, i < n_streamed
     int lds_total;               // dynamic LDS bytes to request
 };
 
@@ -108,10 +109,11 @@ struct MlpEngine {
     char* lds;
     int lane, g, wave, nwaves;
     int ring_pos;  // number of streamed layers consumed so far (slot = ring_pos & 1)
+    int snext;     // position in plan.streamed[] of the next layer to fetch (wraps: the sequence is cyclic)
     Stamper st;    // diagnostic flavor only (empty otherwise)
 
     AC_DI MlpEngine(const MlpPlan& pl, const float* blob, char* lds_base)
-        : plan(pl), gblob(blob), lds(lds_base), ring_pos(0) {
+        : plan(pl), gblob(blob), lds(lds_base), ring_pos(0), snext(pl.n_streamed > 1 ? 1 : 0) {
         lane = threadIdx.x & 63; g = lane >> 4; wave = threadIdx.x >> 6; nwaves = blockDim.x >> 6;
     }
 
@@ -310,7 +312,8 @@ struct MlpEngine {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const char* wl = lds + plan.ring_off[ring_pos & 1];
-        const int nl = streamed_layer((ring_pos + 1) % plan.n_streamed);
+        const int nl = plan.streamed[snext];  // one scalar load (was: a scan of lds_off[] and a modulo per call)
+        snext = (snext + 1 == plan.n_streamed) ? 0 : snext + 1;
         lds_dma_copy(gblob + plan.g_off[nl], lds + plan.ring_off[(ring_pos + 1) & 1], plan.bytes[nl], wave, nwaves,
                      lane);
         ++ring_pos;

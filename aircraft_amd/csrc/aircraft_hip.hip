@@ -305,6 +305,8 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
             pl.ring_off[0] = off; pl.ring_off[1] = off + big;
             pl.lds_total = off + 2 * big;
         }
+        for (int l = 0, i = 0; l < n_layers; ++l)
+            if (pl.lds_off[l] < 0) pl.streamed[i++] = l;
     }
     float* d = nullptr;
     AC_HIP(hipMalloc(&d, total_floats * sizeof(float)));
