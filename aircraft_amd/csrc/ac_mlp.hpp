@@ -28,7 +28,7 @@ struct MlpPlan {
     int n_layers;
     int KT[AC_MAX_LAYERS];       // ceil(n_in / 16)
     int NT[AC_MAX_LAYERS];       // ceil(n_out / 16)
-    int act[AC_MAX_LAYERS];      // 0 identity, 1 tanh
+    int act[AC_MAX_LAYERS];      // 0 identity, 1 tanh; ac_set_mlp guarantees 1 on every layer but the last
     int g_off[AC_MAX_LAYERS];    // float offset of the packed layer block in the global blob
     int bytes[AC_MAX_LAYERS];    // block size: NT*KT*1024 (weights) + 1024 (bias piece)
     int lds_off[AC_MAX_LAYERS];  // byte offset if resident, -1 if streamed through the ring
@@ -140,8 +140,11 @@ struct MlpEngine {
     AC_DI void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
     // Epilogue of one output tile: activation on the value slab, act'(h) scaling on a tangent slab.
-    template <int NT>
-    AC_DI void epilogue_tile(int s, int nt, const f32x4 (&o)[NT], int act) {
+    // ACT: 1 = tanh, 0 = identity, -1 = decided by the runtime flag (a select per element; the hidden layers, where the
+    // epilogue is exposed VALU time, are dispatched on the flag once per layer instead)
+    template <int NT, int ACT = -1>
+    AC_DI void epilogue_tile(int s, int nt, const f32x4 (&o)[NT], int act_flag) {
+        const bool act = ACT < 0 ? act_flag != 0 : ACT != 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (s == 0 || !kDeriv) {
@@ -161,16 +164,14 @@ struct MlpEngine {
 
     // CNT output tiles (independent accumulators) x KT k-tiles for slab s; straight-line code, the next
     // block's A fragments are fetched (ds_read_b128) while the current one's MFMAs issue.  The epilogue of
-    // the PREVIOUS slab (VALU / transcendental work, independent of this slab's MFMAs) is spread over the
-    // k-tile blocks so it issues in the shadow of the matrix pipe instead of after it.
-    template <int CNT, int KT, int NT>
+    // the PREVIOUS slab (VALU / transcendental work, independent of this slab's MFMAs) runs after the first block.
+    template <int CNT, int KT, int NT, int ACT>
     AC_DI void gemm_chunk(const f32x4* __restrict__ wf, const f32x4* __restrict__ bias4, int s, int nc, f32x4 (&o)[NT],
                           const float (&in)[WT][4], const f32x4 (&oprev)[NT], int act, f32x4 (&wcur)[CNT],
                           bool prefetch_next_chunk) {
         // The chunks of a layer are mutually independent; without a fence the machine scheduler interleaves
         // them across the whole straight-line layer and the live accumulators no longer fit the register file.
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int kBlocks = (NT / CNT) * KT;  // k-tile blocks per slab
         f32x4 acc[CNT];
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
@@ -201,11 +202,22 @@ struct MlpEngine {
             for (int r = 1; r < 4; ++r)
 #pragma unroll
                 for (int i = 0; i < CNT; ++i) acc[i] = mma_16x16x4<USE_MFMA>(wcur[i][r], in[kt][r], acc[i]);
-            if (s > 0) {  // previous slab's epilogue tiles assigned to this block
-                const int blk = (nc / CNT) * KT + kt;
+            if (s > 0) {
+                // The previous slab's whole epilogue, as ONE uninterrupted run of VALU work after this slab's first
+                // block.  With one wave per SIMD nothing issues in the shadow of the matrix pipe: every switch
+                // MFMA -> VALU -> MFMA idles it (profiles/r01_micro_mfma_valu_overlap.txt: one v_fma between two MFMAs
+                // costs 15.5 cycles, eight in one run 72), so the epilogue is kept in one piece rather than spread
+                // over the k-tile blocks (measured: 1 tile per 2 blocks 4.145 ms, 2 tiles 4.125, 4 tiles 4.12, all 8
+                // 4.107; later blocks than the first are slower too).  Deferring it to the next slab still pays: the
+                // accumulators it reads are long complete.
+                // (The fences stay in every block of the slab: without them the scheduler reorders the later blocks
+                // and the kernel spills 80 B/lane more.)
+                __builtin_amdgcn_sched_barrier(0);
+                if (nc == 0 && kt == 0) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    if (t * kBlocks / NT == blk) epilogue_tile<NT>(s - 1, t, oprev, act);
+                    for (int t = 0; t < NT; ++t) epilogue_tile<NT, ACT>(s - 1, t, oprev, act);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (fetch) {
 #pragma unroll
@@ -220,7 +232,7 @@ struct MlpEngine {
     // One Linear(+tanh) layer of static shape KT x NT tiles on all slabs.  wl: LDS address of the packed block.
     // The host pads every hidden width to 16*WT, so only the shapes <1,WT> (first), <WT,WT> (hidden),
     // <WT,1> (last) and <1,1> (single-layer net) occur.
-    template <int KT, int NT>
+    template <int KT, int NT, int ACT = -1>
     AC_DI void layer(const char* wl, int act) {
         const f32x4* wf = reinterpret_cast<const f32x4*>(wl) + lane;
         const f32x4* bias4 = reinterpret_cast<const f32x4*>(wl + NT * KT * 1024);
@@ -235,19 +247,20 @@ struct MlpEngine {
 #pragma unroll
             for (int nc = 0; nc < NT; nc += C) {
                 const bool more = !(s == NSLAB - 1 && nc + C >= NT);
-                gemm_chunk<C, KT, NT>(wf, bias4, s, nc, o[s & 1], a[s], o[(s + 1) & 1], act, wcur, more);
+                gemm_chunk<C, KT, NT, ACT>(wf, bias4, s, nc, o[s & 1], a[s], o[(s + 1) & 1], act, wcur, more);
             }
             if (KT == WT && NT == WT) { if (s == 0) AC_MARK(st, 9); else if (s == 1) AC_MARK(st, 10); else AC_MARK(st, 11); }
         }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) epilogue_tile<NT>(NSLAB - 1, nt, o[(NSLAB - 1) & 1], act);
+        for (int nt = 0; nt < NT; ++nt) epilogue_tile<NT, ACT>(NSLAB - 1, nt, o[(NSLAB - 1) & 1], act);
     }
 
     // First layer (5 -> width), tangent-aware: the value slab runs on the MFMA (one padded k-tile); the tangent
     // slabs of the first layer are just columns of W0 scaled by act'(h) — W0[n][j] (1 - h_n^2) — so they are read
     // from a transposed copy of W0 the host appends to the block, with no MFMA at all (saves 5/6 of this layer's
     // matrix work, 3 % of a stage).
-    AC_DI void layer_first(const char* wl, int act) {
+    AC_DI void layer_first(const char* wl) {
+        constexpr bool act = true;  // not the last layer (see forward()): always tanh after the host-side fold
         const f32x4* wf = reinterpret_cast<const f32x4*>(wl) + lane;
         const f32x4* bias4 = reinterpret_cast<const f32x4*>(wl + WT * 1024);
         const f32x4* w0t = reinterpret_cast<const f32x4*>(wl + WT * 1024 + 1024);  // [5][16*WT] floats
@@ -263,7 +276,7 @@ struct MlpEngine {
                 o[nt] = acc;
             }
 #pragma unroll
-            for (int nt = 0; nt < WT; ++nt) epilogue_tile<WT>(sv, nt, o, act);
+            for (int nt = 0; nt < WT; ++nt) epilogue_tile<WT, 1>(sv, nt, o, 1);
         }
         if constexpr (kTangent) {
             // tile by tile: the W0 columns of all tangents are requested together (one LDS wait per tile, not one per
@@ -362,13 +375,13 @@ struct MlpEngine {
         if (L == 1) {
             layer<1, 1>(acquire(0), plan.act[0]);
         } else {
-            layer_first(acquire(0), plan.act[0]);
+            layer_first(acquire(0));
             AC_MARK(st, 2);  // [2] first layer
 #pragma nounroll
             for (int l = 1; l < L - 1; ++l) {
                 const char* wl = acquire(l);
                 AC_MARK(st, 3);  // [3] acquire: DMA wait + barrier + DMA issue
-                layer<WT, WT>(wl, plan.act[l]);
+                layer<WT, WT, 1>(wl, 1);  // tanh on every layer but the last: ac_set_mlp folds activation-free layers away
                 AC_MARK(st, 4);  // [4] hidden layer GEMM + epilogues
             }
             layer<WT, 1>(acquire(L - 1), plan.act[L - 1]);

@@ -235,6 +235,46 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
             return AC_ERR_UNSUPPORTED;
         }
     }
+    // Fold every activation-free layer that is not the last into its successor (in float64):
+    //   W2 (W1 x + b1) + b2 = (W2 W1) x + (W2 b1 + b2).
+    // The device engines then see tanh on every layer but the last (a compile-time fact in the hidden-layer epilogues,
+    // which are exposed VALU time) and the reference checkpoint's Linear-Linear-Tanh-Linear net (surrogates/models.py:
+    // 114-123) runs as 5-32-6 instead of 5-16-32-6.
+    struct HostLayer { int nin, nout, act; std::vector<double> W, b; };
+    std::vector<HostLayer> net((size_t)n_layers);
+    for (int l = 0; l < n_layers; ++l) {
+        if (!W[l] || !b[l]) return AC_ERR_BAD_ARG;
+        HostLayer& L = net[(size_t)l];
+        L.nin = widths[l]; L.nout = widths[l + 1]; L.act = act[l] ? 1 : 0;
+        L.W.assign(W[l], W[l] + (size_t)L.nin * L.nout);
+        L.b.assign(b[l], b[l] + L.nout);
+    }
+    for (size_t l = 0; l + 1 < net.size();) {
+        if (net[l].act) { ++l; continue; }
+        const HostLayer &A = net[l], &B = net[l + 1];
+        HostLayer M;
+        M.nin = A.nin; M.nout = B.nout; M.act = B.act;
+        M.W.assign((size_t)M.nin * M.nout, 0.0);
+        M.b = B.b;
+        for (int i = 0; i < B.nout; ++i)
+            for (int k = 0; k < B.nin; ++k) {
+                const double w = B.W[(size_t)i * B.nin + k];
+                M.b[(size_t)i] += w * A.b[(size_t)k];
+                for (int j = 0; j < A.nin; ++j) M.W[(size_t)i * M.nin + j] += w * A.W[(size_t)k * A.nin + j];
+            }
+        net[l] = std::move(M);
+        net.erase(net.begin() + (long)l + 1);
+    }
+    n_layers = (int)net.size();
+    std::vector<int> fwidths((size_t)n_layers + 1);
+    std::vector<std::vector<float>> fW((size_t)n_layers), fb((size_t)n_layers);
+    fwidths[0] = net[0].nin;
+    for (int l = 0; l < n_layers; ++l) {
+        fwidths[(size_t)l + 1] = net[(size_t)l].nout;
+        fW[(size_t)l].assign(net[(size_t)l].W.begin(), net[(size_t)l].W.end());
+        fb[(size_t)l].assign(net[(size_t)l].b.begin(), net[(size_t)l].b.end());
+    }
+    widths = fwidths.data();
     MlpPlan pl;
     memset(&pl, 0, sizeof(pl));
     pl.n_layers = n_layers;
@@ -247,10 +287,9 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
     const int wt = maxt <= 2 ? 2 : (maxt <= 4 ? 4 : 8);
     size_t total_floats = 0;
     for (int l = 0; l < n_layers; ++l) {
-        if (!W[l] || !b[l]) return AC_ERR_BAD_ARG;
         pl.KT[l] = (l == 0) ? 1 : wt;
         pl.NT[l] = (l == n_layers - 1) ? 1 : wt;
-        pl.act[l] = act[l] ? 1 : 0;
+        pl.act[l] = net[(size_t)l].act;  // 1 for every l < n_layers - 1 after the fold
         pl.bytes[l] = pl.NT[l] * pl.KT[l] * 1024 + 1024;  // weights + one 1-KiB bias piece (whole LDS-DMA pieces only)
         // first layer of a multi-layer net: + W0 transposed [5][16*wt] for the MFMA-free tangent slabs
         if (l == 0 && n_layers > 1) pl.bytes[l] += ((5 * wt * 64 + 1023) / 1024) * 1024;
@@ -268,14 +307,14 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
                     for (int j = 0; j < 4; ++j) {
                         const int row = 16 * nt + (lane & 15), k = 16 * kt + 4 * (lane >> 4) + j;
                         dst[((size_t)(nt * KT + kt) * 64 + lane) * 4 + j] =
-                            (row < nout && k < nin) ? W[l][(size_t)row * nin + k] : 0.f;
+                            (row < nout && k < nin) ? fW[(size_t)l][(size_t)row * nin + k] : 0.f;
                     }
         float* bd = dst + (size_t)NT * KT * 256;
-        for (int i = 0; i < NT * 16; ++i) bd[i] = i < nout ? b[l][i] : 0.f;
+        for (int i = 0; i < NT * 16; ++i) bd[i] = i < nout ? fb[(size_t)l][(size_t)i] : 0.f;
         if (l == 0 && n_layers > 1) {
             float* wt0 = bd + 256;  // after the 1-KiB bias piece
             for (int j = 0; j < 5; ++j)
-                for (int n = 0; n < wt * 16; ++n) wt0[j * wt * 16 + n] = n < nout ? W[l][(size_t)n * nin + j] : 0.f;
+                for (int n = 0; n < wt * 16; ++n) wt0[j * wt * 16 + n] = n < nout ? fW[(size_t)l][(size_t)n * nin + j] : 0.f;
         }
     }
     // LDS plan: everything resident if it fits; otherwise the largest layers stream through a 2-slot ring.

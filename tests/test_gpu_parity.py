@@ -231,6 +231,34 @@ def test_shooting_layout_in_place(gpu, model):
     assert float(ms.defects(Xtraj, dev(U, gpu)).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("act", [[1, 0, 1, 0], [0, 0, 1, 1], [0, 1, 0, 0], [0, 0, 0, 0], [1, 1, 1, 1]])
+def test_activation_free_layers_are_folded(gpu, act):
+    """ac_set_mlp folds every activation-free layer that is not the last into its successor (the engines assume tanh on
+    all layers but the last).  The oracle evaluates the net as given: any pattern of tanh / identity layers — including a
+    tanh on the output layer and an all-linear net — must agree through step, sensitivities and second-order blocks."""
+    from aircraft_amd import Aircraft, AircraftConfiguration, AircraftOpts, MlpData
+    from tests.helpers import GLIDER, oracle_step_hessian
+
+    base = MlpData.synthetic((48, 24, 40), seed=5)
+    md = MlpData(base.weights, base.biases, act, base.input_mean, base.input_std, base.output_mean, base.output_std)
+    ac = Aircraft(AircraftOpts(coeff_model_type="nn", coeff_model_path=md, aircraft_config=AircraftConfiguration(dict(GLIDER)),
+                               physical_integration_substeps=1))
+    ac.normalise = True
+    X, U = synthetic_units(150, seed=31, flaps=True)
+    Xn, A, Bm, c = ac.step_sens(dev(X, gpu), dev(U, gpu), 0.01)
+    orc = make_oracle(ac)
+    Xr, Ar, Br, cr = orc.step_sens(X, U, 0.01)
+    assert block_rel_err(Xn.cpu().numpy(), Xr) < STATE_TOL
+    assert rel_fro(A.cpu().numpy(), Ar) < SENS_TOL and rel_fro(Bm.cpu().numpy(), Br) < SENS_TOL
+    assert rel_fro(c.cpu().numpy(), cr) < SENS_TOL
+    assert block_rel_err(ac.state_update(dev(X, gpu), dev(U, gpu), 0.01).cpu().numpy(), Xr) < STATE_TOL
+    lam = np.random.default_rng(3).standard_normal((13, 150))
+    lam = f32_exact(lam)
+    Hd = ac.step_hess(dev(X, gpu), dev(U, gpu), 0.01, dev(lam, gpu)).cpu().numpy()
+    Hr = oracle_step_hessian(orc, X, U, 0.01, lam)
+    assert rel_fro(Hd, Hr) < 2e-3
+
+
 def test_mfma_and_valu_paths_agree(gpu):
     """v_mfma_f32_16x16x4_f32 is an exact k-ordered fp32 fma chain; the VALU cross-lane path does the same
     contraction, so the two must agree to the last bit or two."""
