@@ -4,8 +4,11 @@
 // second-derivative tensor T = d2y/dz dz (6 x 15 symmetric pairs) at the four stage points, and those points depend on
 // the PRIMAL trajectory of the step alone:
 //   k_nn_stage_tensors   walks the primal RK4 stages of 16 units per wave and evaluates y, J, T at each stage with the
-//                        MFMA engine in second-order mode: per pass the slabs are value, d/dz_p, d/dz_q, d2/dz_p2,
-//                        d2/dz_q2, d2/dz_p dz_q for one input pair (p, q); ten passes cover all pairs of the five inputs.
+//                        MFMA engine in second-order mode: per pass ten slabs — value, the three first and the six second
+//                        derivatives for one input triple (p, q, r) — which this kernel's register file holds because it
+//                        carries no dual RK4 state; four triples {0,1,2} {0,3,4} {1,3,4} {2,3,4} cover all fifteen pairs
+//                        of the five inputs: 40 slab evaluations per stage (ten passes over input PAIRS with six slabs
+//                        each needed 60).
 //                        Output per unit: [4 stages][126 = 6 + 30 + 90] floats.
 //   k_step_hess<NN>      (ac_hess.hpp) the same second-order forward-mode kernel as for the analytic models, with a
 //                        coefficient provider that applies the chain rule through the stored (y, J, T).
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors(const DevParams 
                                                                 float dt, const float* __restrict__ dt_per_unit, long n,
                                                                 long blk, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    MlpEngine<6, WT, USE_MFMA, false, true> eng(plan, blob, smem);
+    MlpEngine<10, WT, USE_MFMA, false, true> eng(plan, blob, smem);
     eng.load_weights();
     const WaveUnit w(n, blk);
     float x0[13], u[7];
@@ -56,31 +59,33 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors(const DevParams 
         for (int j = 0; j < 5; ++j) z[j] = (in[j] - P.mlp_in_mean[j]) / P.mlp_in_std[j];
         GivenY prov;
         float* o = out + w.ua.off(kStageFloats) + (long)s * kStageRows * blk;
-        int pass = 0;
 #pragma nounroll
-        for (int p = 0; p < 4; ++p) {
-#pragma nounroll
-            for (int q = p + 1; q < 5; ++q, ++pass) {
-                eng.set_pair(p, q);
-                float yy[6], D[6][5];
-                eng.forward(z, yy, D);
+        for (int pass = 0; pass < 4; ++pass) {
+            // triples {0,1,2} {0,3,4} {1,3,4} {2,3,4}
+            const int tp = pass < 2 ? 0 : pass - 1, tq = pass == 0 ? 1 : 3, tr = pass == 0 ? 2 : 4;
+            eng.set_triple(tp, tq, tr);
+            float yy[6], D[6][9];
+            eng.forward(z, yy, D);
+            if (pass == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) prov.y[k] = yy[k];
+            }
+            if (w.live && w.g == pass) {  // the four lane groups of a unit hold the same results: one pass each
                 if (pass == 0) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) prov.y[k] = yy[k];
+                    for (int k = 0; k < 6; ++k) o[(long)k * blk] = yy[k];
                 }
-                if (w.live && w.g == (pass & 3)) {  // the four lane groups of a unit hold the same results
-                    if (pass == 0) {
+                const int t3[3] = {tp, tq, tr};
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) o[(long)k * blk] = yy[k];
-                    }
+                for (int k = 0; k < 6; ++k) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        o[(long)(6 + k * 5 + p) * blk] = D[k][0];
-                        o[(long)(6 + k * 5 + q) * blk] = D[k][1];
-                        o[(long)(36 + k * 15 + pair_index(p, p)) * blk] = D[k][2];
-                        o[(long)(36 + k * 15 + pair_index(q, q)) * blk] = D[k][3];
-                        o[(long)(36 + k * 15 + pair_index(p, q)) * blk] = D[k][4];
+                    for (int i = 0; i < 3; ++i) {
+                        o[(long)(6 + k * 5 + t3[i]) * blk] = D[k][i];
+                        o[(long)(36 + k * 15 + pair_index(t3[i], t3[i])) * blk] = D[k][3 + i];
                     }
+                    o[(long)(36 + k * 15 + pair_index(tp, tq)) * blk] = D[k][6];
+                    o[(long)(36 + k * 15 + pair_index(tp, tr)) * blk] = D[k][7];
+                    o[(long)(36 + k * 15 + pair_index(tq, tr)) * blk] = D[k][8];
                 }
             }
         }

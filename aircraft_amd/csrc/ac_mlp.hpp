@@ -88,19 +88,24 @@ AC_DI void lds_dma_copy(const float* __restrict__ gsrc, char* lds_dst, int bytes
 // NSLAB slabs of 16 columns each.  TANGENT: slab 0 carries values and slabs 1..5 the five input tangents of the SAME
 // 16 units (NSLAB = 6).  Otherwise every slab is a value slab: NSLAB = 1 (16 units, the four lanes of a unit redundant)
 // or NSLAB = 4 (64 units, lane = unit; slab s = units 16 s .. 16 s + 15).  WT: register tiles per slab = width / 16.
-// SECOND (second-order mode, NSLAB == 6): slabs = value, d/dz_p, d/dz_q, d2/dz_p2, d2/dz_q2, d2/dz_p dz_q for one
-// input pair (p, q) set with set_pair(); used by the Hessian path (ac_hess_nn.hpp), never by the step kernels.
+// SECOND (second-order mode, NSLAB == 10): slabs = value, the three first and the six second derivatives for one
+// input triple (p, q, r) set with set_triple(); used by the Hessian path (ac_hess_nn.hpp), never by the step kernels.
 // TOFF (tangent mode with fewer slabs): tangent slab s carries input TOFF + s - 1 — a wave pair splits the five
 // tangents as value + {0, 1, 2} and value + {3, 4} (k_nn_step_sens_pair).
 template <int NSLAB, int WT, bool USE_MFMA, bool TANGENT = (NSLAB == 6), bool SECOND = false, int TOFF = 0>
 struct MlpEngine {
     static_assert(!TANGENT || (NSLAB >= 2 && NSLAB <= 6 && TOFF + NSLAB - 1 <= 5), "tangent mode = value + a range of the 5 input tangents");
     static constexpr int kTangents = TANGENT ? NSLAB - 1 : 0;
-    static_assert(!SECOND || (NSLAB == 6 && !TANGENT), "second-order mode = value + 2 first-order + 3 second-order slabs");
+    // second-order mode, for an input triple (p, q, r): slab 0 value; 1-3 d/dz_p, d/dz_q, d/dz_r; 4-6 d2/dz_p2, d2/dz_q2,
+    // d2/dz_r2; 7-9 d2/dz_p dz_q, d2/dz_p dz_r, d2/dz_q dz_r
+    static_assert(!SECOND || (NSLAB == 10 && !TANGENT), "second-order mode = value + 3 first-order + 6 second-order slabs");
+    static constexpr int kFirstOrder = SECOND ? 3 : 0;  // slabs 1..kFirstOrder of the second-order mode are first-order
+    AC_DI static constexpr int second_a(int s) { return s == 4 ? 1 : s == 5 ? 2 : s == 6 ? 3 : s == 9 ? 2 : 1; }
+    AC_DI static constexpr int second_b(int s) { return s == 4 ? 1 : s == 5 ? 2 : s == 7 ? 2 : 3; }
     static constexpr bool kTangent = TANGENT;
     static constexpr bool kDeriv = TANGENT || SECOND;  // slabs > 0 are derivative slabs (no bias, chain-rule epilogue)
-    int pair_p = 0, pair_q = 1;
-    AC_DI void set_pair(int p, int q) { pair_p = p; pair_q = q; }
+    int tri[3] = {0, 1, 2};
+    AC_DI void set_triple(int p, int q, int r) { tri[0] = p; tri[1] = q; tri[2] = r; }
     static constexpr int CH = WT < 4 ? WT : 4;  // output tiles computed together (independent accumulators)
 
     float a[NSLAB][WT][4];
@@ -149,13 +154,13 @@ struct MlpEngine {
         for (int r = 0; r < 4; ++r) {
             if (s == 0 || !kDeriv) {
                 a[s][nt][r] = act ? act_tanh(o[nt][r]) : o[nt][r];
-            } else if (!SECOND || s <= 2) {
+            } else if (!SECOND || s <= kFirstOrder) {
                 const float h = a[0][nt][r];  // already the NEW value activation
                 a[s][nt][r] = act ? o[nt][r] * fmaf(-h, h, 1.0f) : o[nt][r];
             } else {
                 // h_ab = s'(z) z_ab + s''(z) z_a z_b with s'' = -2 h s' and z_a = h_a / s'  (h_a, h_b already NEW)
                 const float h = a[0][nt][r], sp = fmaf(-h, h, 1.0f);
-                const float ha = a[s == 4 ? 2 : 1][nt][r], hb = a[s == 3 ? 1 : 2][nt][r];
+                const float ha = a[second_a(s)][nt][r], hb = a[second_b(s)][nt][r];
                 const float inv = sp > 1e-30f ? 1.0f / sp : 0.f;  // saturated neuron: both terms vanish
                 a[s][nt][r] = act ? fmaf(o[nt][r], sp, -2.0f * h * ha * hb * inv) : o[nt][r];
             }
@@ -302,17 +307,18 @@ struct MlpEngine {
             // z = W0 in + b is linear in the inputs: h_a = s' W0[:, a], h_ab = s'' W0[:, a] W0[:, b] = -2 h h_a W0[:, b]
 #pragma unroll
             for (int nt = 0; nt < WT; ++nt) {
-                const f32x4 wp = w0t[pair_p * (WT * 4) + 4 * nt + g];
-                const f32x4 wq = w0t[pair_q * (WT * 4) + 4 * nt + g];
+                f32x4 w[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) w[i] = w0t[tri[i] * (WT * 4) + 4 * nt + g];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float h = a[0][nt][r], sp = fmaf(-h, h, 1.0f);
-                    const float hp = act ? wp[r] * sp : wp[r], hq = act ? wq[r] * sp : wq[r];
-                    a[1][nt][r] = hp;
-                    a[2][nt][r] = hq;
-                    a[3][nt][r] = act ? -2.0f * h * hp * wp[r] : 0.f;
-                    a[4][nt][r] = act ? -2.0f * h * hq * wq[r] : 0.f;
-                    a[5][nt][r] = act ? -2.0f * h * hp * wq[r] : 0.f;
+                    const float h = a[0][nt][r], sp = fmaf(-h, h, 1.0f), m2h = -2.0f * h;
+                    float ha[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { ha[i] = w[i][r] * sp; a[1 + i][nt][r] = ha[i]; }
+#pragma unroll
+                    for (int sl = 4; sl < 10; ++sl)  // h_ab = s'' w_a w_b = -2 h (s' w_a) w_b
+                        a[sl][nt][r] = m2h * ha[second_a(sl) - 1] * w[second_b(sl) - 1][r];
                 }
             }
         }
@@ -336,7 +342,8 @@ struct MlpEngine {
     // y[6] (and J[6][5] = dy/dz in tangent mode) of the raw network for normalised inputs z[5].
     // Every lane of a unit passes the same z and receives the same outputs.  Wave-collective and,
     // when layers are streamed, workgroup-collective (one barrier per streamed layer).
-    AC_DI void forward(const float z[5], float y[6], float (*J)[5]) {
+    template <int JC> AC_DI void forward(const float z[5], float y[6], float (*J)[JC]) {
+        static_assert(!kDeriv || JC >= NSLAB - 1, "J holds one column per derivative slab");
         const int col = lane & 15;
         if constexpr (!kDeriv && NSLAB > 1) {
             // multi-value mode: lane = unit.  Slab s needs z of unit 16 s + col in rows 0..4 (row k on lane group k>>2).
@@ -364,9 +371,10 @@ struct MlpEngine {
                     for (int j = 0; j < kTangents; ++j) a[1 + j][0][r] = (row == TOFF + j) ? 1.f : 0.f;
                 }
                 if constexpr (SECOND) {
-                    a[1][0][r] = (row == pair_p) ? 1.f : 0.f;
-                    a[2][0][r] = (row == pair_q) ? 1.f : 0.f;
-                    a[3][0][r] = 0.f; a[4][0][r] = 0.f; a[5][0][r] = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) a[1 + i][0][r] = (row == tri[i]) ? 1.f : 0.f;
+#pragma unroll
+                    for (int sl = 4; sl < 10; ++sl) a[sl][0][r] = 0.f;
                 }
             }
         }
@@ -404,7 +412,7 @@ struct MlpEngine {
             for (int k = 0; k < 6; ++k) {
                 const int src = col + 16 * (k >> 2);
                 y[k] = __shfl(a[0][0][k & 3], src, 64);
-                if constexpr (kDeriv) {  // SECOND: J[k][0..4] = dy/dz_p, dy/dz_q, d2y/dz_p2, d2y/dz_q2, d2y/dz_p dz_q
+                if constexpr (kDeriv) {  // SECOND: J[k][0..8] = d/dz_{p,q,r}, d2/dz_{p,q,r}2, d2/dz_{pq,pr,qr}
 #pragma unroll
                     for (int j = 0; j < NSLAB - 1; ++j) J[k][j] = __shfl(a[1 + j][0][k & 3], src, 64);  // partial: local columns
                 }
