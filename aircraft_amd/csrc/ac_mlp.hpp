@@ -92,8 +92,20 @@ AC_DI void lds_dma_copy(const float* __restrict__ gsrc, char* lds_dst, int bytes
 // input triple (p, q, r) set with set_triple(); used by the Hessian path (ac_hess_nn.hpp), never by the step kernels.
 // TOFF (tangent mode with fewer slabs): tangent slab s carries input TOFF + s - 1 — a wave pair splits the five
 // tangents as value + {0, 1, 2} and value + {3, 4} (k_nn_step_sens_pair).
+// The input triple of the second-order mode lives in a base class that is EMPTY for every other engine: a member the
+// step kernels never read still moved hipcc's register allocation of k_nn_step_sens (scratch 228 -> 264 B, -1.2 %).
+template <bool ON> struct TripleHolder {
+    int tri_p = 0, tri_q = 1, tri_r = 2;
+    AC_DI void set_triple(int p, int q, int r) { tri_p = p; tri_q = q; tri_r = r; }
+    AC_DI int tri(int i) const { return i == 0 ? tri_p : i == 1 ? tri_q : tri_r; }
+};
+template <> struct TripleHolder<false> {
+    AC_DI int tri(int) const { return 0; }
+};
+
 template <int NSLAB, int WT, bool USE_MFMA, bool TANGENT = (NSLAB == 6), bool SECOND = false, int TOFF = 0>
-struct MlpEngine {
+struct MlpEngine : TripleHolder<SECOND> {
+    using TripleHolder<SECOND>::tri;
     static_assert(!TANGENT || (NSLAB >= 2 && NSLAB <= 6 && TOFF + NSLAB - 1 <= 5), "tangent mode = value + a range of the 5 input tangents");
     static constexpr int kTangents = TANGENT ? NSLAB - 1 : 0;
     // second-order mode, for an input triple (p, q, r): slab 0 value; 1-3 d/dz_p, d/dz_q, d/dz_r; 4-6 d2/dz_p2, d2/dz_q2,
@@ -104,8 +116,6 @@ struct MlpEngine {
     AC_DI static constexpr int second_b(int s) { return s == 4 ? 1 : s == 5 ? 2 : s == 7 ? 2 : 3; }
     static constexpr bool kTangent = TANGENT;
     static constexpr bool kDeriv = TANGENT || SECOND;  // slabs > 0 are derivative slabs (no bias, chain-rule epilogue)
-    int tri[3] = {0, 1, 2};
-    AC_DI void set_triple(int p, int q, int r) { tri[0] = p; tri[1] = q; tri[2] = r; }
     static constexpr int CH = WT < 4 ? WT : 4;  // output tiles computed together (independent accumulators)
 
     float a[NSLAB][WT][4];
@@ -309,7 +319,7 @@ struct MlpEngine {
             for (int nt = 0; nt < WT; ++nt) {
                 f32x4 w[3];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) w[i] = w0t[tri[i] * (WT * 4) + 4 * nt + g];
+                for (int i = 0; i < 3; ++i) w[i] = w0t[tri(i) * (WT * 4) + 4 * nt + g];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float h = a[0][nt][r], sp = fmaf(-h, h, 1.0f), m2h = -2.0f * h;
@@ -372,7 +382,7 @@ struct MlpEngine {
                 }
                 if constexpr (SECOND) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) a[1 + i][0][r] = (row == tri[i]) ? 1.f : 0.f;
+                    for (int i = 0; i < 3; ++i) a[1 + i][0][r] = (row == tri(i)) ? 1.f : 0.f;
 #pragma unroll
                     for (int sl = 4; sl < 10; ++sl) a[sl][0][r] = 0.f;
                 }
