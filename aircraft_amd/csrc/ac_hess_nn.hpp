@@ -8,7 +8,7 @@
 //                        derivatives for one input triple (p, q, r) — which this kernel's register file holds because it
 //                        carries no dual RK4 state; four triples {0,1,2} {0,3,4} {1,3,4} {2,3,4} cover all fifteen pairs
 //                        of the five inputs: 40 slab evaluations per stage (ten passes over input PAIRS with six slabs
-//                        each needed 60).
+//                        each needed 60).  Widths <= 64: one pass of 21 slabs over all five inputs.
 //                        Output per unit: [4 stages][126 = 6 + 30 + 90] floats.
 //   k_step_hess<NN>      (ac_hess.hpp) the same second-order forward-mode kernel as for the analytic models, with a
 //                        coefficient provider that applies the chain rule through the stored (y, J, T).
@@ -39,7 +39,9 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors(const DevParams 
                                                                 float dt, const float* __restrict__ dt_per_unit, long n,
                                                                 long blk, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    MlpEngine<10, WT, USE_MFMA, false, true> eng(plan, blob, smem);
+    // width <= 64: all five inputs in one pass (21 slabs of 4 WT registers); width 128: four passes over input triples
+    constexpr bool kSingle = WT <= 4;
+    MlpEngine<kSingle ? 21 : 10, WT, USE_MFMA, false, true> eng(plan, blob, smem);
     eng.load_weights();
     const WaveUnit w(n, blk);
     float x0[13], u[7];
@@ -59,6 +61,34 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors(const DevParams 
         for (int j = 0; j < 5; ++j) z[j] = (in[j] - P.mlp_in_mean[j]) / P.mlp_in_std[j];
         GivenY prov;
         float* o = out + w.ua.off(kStageFloats) + (long)s * kStageRows * blk;
+        if constexpr (kSingle) {
+            float yy[6], D[6][20];  // D[k] = d/dz_0..4, d2/dz_0..4 ^2, then the mixed pairs (0,1) (0,2) .. (3,4)
+            eng.forward(z, yy, D);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) prov.y[k] = yy[k];
+            if (w.live) {  // the four lane groups of a unit hold the same results: y and J from group 0, T split by output
+                if (w.g == 0) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        o[(long)k * blk] = yy[k];
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) o[(long)(6 + k * 5 + i) * blk] = D[k][i];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    if (w.g == 1 + (k >> 1)) {
+                        int m = 10;
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) {
+                            o[(long)(36 + k * 15 + pair_index(i, i)) * blk] = D[k][5 + i];
+#pragma unroll
+                            for (int j = i + 1; j < 5; ++j, ++m) o[(long)(36 + k * 15 + pair_index(i, j)) * blk] = D[k][m];
+                        }
+                    }
+                }
+            }
+        } else {
 #pragma nounroll
         for (int pass = 0; pass < 4; ++pass) {
             // triples {0,1,2} {0,3,4} {1,3,4} {2,3,4}
@@ -88,6 +118,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors(const DevParams 
                     o[(long)(36 + k * 15 + pair_index(tq, tr)) * blk] = D[k][8];
                 }
             }
+        }
         }
         if (s < 3) {  // next primal stage point
             float k1[13];

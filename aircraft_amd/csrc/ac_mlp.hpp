@@ -88,8 +88,9 @@ AC_DI void lds_dma_copy(const float* __restrict__ gsrc, char* lds_dst, int bytes
 // NSLAB slabs of 16 columns each.  TANGENT: slab 0 carries values and slabs 1..5 the five input tangents of the SAME
 // 16 units (NSLAB = 6).  Otherwise every slab is a value slab: NSLAB = 1 (16 units, the four lanes of a unit redundant)
 // or NSLAB = 4 (64 units, lane = unit; slab s = units 16 s .. 16 s + 15).  WT: register tiles per slab = width / 16.
-// SECOND (second-order mode, NSLAB == 10): slabs = value, the three first and the six second derivatives for one
-// input triple (p, q, r) set with set_triple(); used by the Hessian path (ac_hess_nn.hpp), never by the step kernels.
+// SECOND (second-order mode): slabs = value, the K first and the K (K + 1) / 2 second derivatives for one input triple
+// (p, q, r) set with set_triple() (NSLAB == 10) or for all five inputs (NSLAB == 21, widths <= 64); used by the Hessian
+// path (ac_hess_nn.hpp), never by the step kernels.
 // TOFF (tangent mode with fewer slabs): tangent slab s carries input TOFF + s - 1 — a wave pair splits the five
 // tangents as value + {0, 1, 2} and value + {3, 4} (k_nn_step_sens_pair).
 // The input triple of the second-order mode lives in a base class that is EMPTY for every other engine: a member the
@@ -104,16 +105,31 @@ template <> struct TripleHolder<false> {
 };
 
 template <int NSLAB, int WT, bool USE_MFMA, bool TANGENT = (NSLAB == 6), bool SECOND = false, int TOFF = 0>
-struct MlpEngine : TripleHolder<SECOND> {
-    using TripleHolder<SECOND>::tri;
+struct MlpEngine : TripleHolder<SECOND && NSLAB == 10> {
+    using TripleHolder<SECOND && NSLAB == 10>::tri;
     static_assert(!TANGENT || (NSLAB >= 2 && NSLAB <= 6 && TOFF + NSLAB - 1 <= 5), "tangent mode = value + a range of the 5 input tangents");
     static constexpr int kTangents = TANGENT ? NSLAB - 1 : 0;
-    // second-order mode, for an input triple (p, q, r): slab 0 value; 1-3 d/dz_p, d/dz_q, d/dz_r; 4-6 d2/dz_p2, d2/dz_q2,
-    // d2/dz_r2; 7-9 d2/dz_p dz_q, d2/dz_p dz_r, d2/dz_q dz_r
-    static_assert(!SECOND || (NSLAB == 10 && !TANGENT), "second-order mode = value + 3 first-order + 6 second-order slabs");
-    static constexpr int kFirstOrder = SECOND ? 3 : 0;  // slabs 1..kFirstOrder of the second-order mode are first-order
-    AC_DI static constexpr int second_a(int s) { return s == 4 ? 1 : s == 5 ? 2 : s == 6 ? 3 : s == 9 ? 2 : 1; }
-    AC_DI static constexpr int second_b(int s) { return s == 4 ? 1 : s == 5 ? 2 : s == 7 ? 2 : 3; }
+    // second-order mode over K inputs (a triple (p, q, r) set with set_triple(), NSLAB = 10; or all five, NSLAB = 21):
+    // slab 0 value; 1..K d/dz_i; K+1..2K d2/dz_i2; then d2/dz_i dz_j for the pairs i < j in lexicographic order
+    // (K = 3: 7-9 = pq, pr, qr).  NSLAB = 1 + K + K (K + 1) / 2.
+    static_assert(!SECOND || ((NSLAB == 10 || NSLAB == 21) && !TANGENT), "second-order mode = value + K first-order + K (K + 1) / 2 second-order slabs, K = 3 or 5");
+    static constexpr int kFirstOrder = !SECOND ? 0 : (NSLAB == 10 ? 3 : 5);  // = K: slabs 1..K are first-order
+    // first-order slabs (1-based input positions) whose product the second-order slab s differentiates
+    AC_DI static constexpr int second_a(int s) {
+        constexpr int K = kFirstOrder;
+        if (s <= 2 * K) return s - K;
+        int m = s - 2 * K - 1;
+        for (int i = 1; i < K; ++i) { if (m < K - i) return i; m -= K - i; }
+        return K;
+    }
+    AC_DI static constexpr int second_b(int s) {
+        constexpr int K = kFirstOrder;
+        if (s <= 2 * K) return s - K;
+        int m = s - 2 * K - 1;
+        for (int i = 1; i < K; ++i) { if (m < K - i) return i + 1 + m; m -= K - i; }
+        return K;
+    }
+    AC_DI int input_of(int i) const { if constexpr (NSLAB == 10) return tri(i); else return i; }
     static constexpr bool kTangent = TANGENT;
     static constexpr bool kDeriv = TANGENT || SECOND;  // slabs > 0 are derivative slabs (no bias, chain-rule epilogue)
     static constexpr int CH = WT < 4 ? WT : 4;  // output tiles computed together (independent accumulators)
@@ -317,17 +333,17 @@ struct MlpEngine : TripleHolder<SECOND> {
             // z = W0 in + b is linear in the inputs: h_a = s' W0[:, a], h_ab = s'' W0[:, a] W0[:, b] = -2 h h_a W0[:, b]
 #pragma unroll
             for (int nt = 0; nt < WT; ++nt) {
-                f32x4 w[3];
+                f32x4 w[kFirstOrder];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) w[i] = w0t[tri(i) * (WT * 4) + 4 * nt + g];
+                for (int i = 0; i < kFirstOrder; ++i) w[i] = w0t[input_of(i) * (WT * 4) + 4 * nt + g];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float h = a[0][nt][r], sp = fmaf(-h, h, 1.0f), m2h = -2.0f * h;
-                    float ha[3];
+                    float ha[kFirstOrder];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) { ha[i] = w[i][r] * sp; a[1 + i][nt][r] = ha[i]; }
+                    for (int i = 0; i < kFirstOrder; ++i) { ha[i] = w[i][r] * sp; a[1 + i][nt][r] = ha[i]; }
 #pragma unroll
-                    for (int sl = 4; sl < 10; ++sl)  // h_ab = s'' w_a w_b = -2 h (s' w_a) w_b
+                    for (int sl = kFirstOrder + 1; sl < NSLAB; ++sl)  // h_ab = s'' w_a w_b = -2 h (s' w_a) w_b
                         a[sl][nt][r] = m2h * ha[second_a(sl) - 1] * w[second_b(sl) - 1][r];
                 }
             }
@@ -382,9 +398,9 @@ struct MlpEngine : TripleHolder<SECOND> {
                 }
                 if constexpr (SECOND) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) a[1 + i][0][r] = (row == tri(i)) ? 1.f : 0.f;
+                    for (int i = 0; i < kFirstOrder; ++i) a[1 + i][0][r] = (row == input_of(i)) ? 1.f : 0.f;
 #pragma unroll
-                    for (int sl = 4; sl < 10; ++sl) a[sl][0][r] = 0.f;
+                    for (int sl = kFirstOrder + 1; sl < NSLAB; ++sl) a[sl][0][r] = 0.f;
                 }
             }
         }
