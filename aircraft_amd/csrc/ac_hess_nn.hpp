@@ -9,6 +9,9 @@
 //                        carries no dual RK4 state; four triples {0,1,2} {0,3,4} {1,3,4} {2,3,4} cover all fifteen pairs
 //                        of the five inputs: 40 slab evaluations per stage (ten passes over input PAIRS with six slabs
 //                        each needed 60).  Widths <= 64: one pass of 21 slabs over all five inputs.
+//                        Width 128 runs as two launches: PART 0 = the triples {0,1,2} and {2,3,4} (ten slabs each),
+//                        PART 1 = one bipartite pass (nine slabs: value, d/dz of 0, 1, 3, 4 and the four cross pairs
+//                        03, 04, 13, 14): 29 slab evaluations per stage.
 //                        Output per unit: [4 stages][126 = 6 + 30 + 90] floats.
 //   k_step_hess<NN>      (ac_hess.hpp) the same second-order forward-mode kernel as for the analytic models, with a
 //                        coefficient provider that applies the chain rule through the stored (y, J, T).
@@ -32,7 +35,7 @@ struct GivenY {
     }
 };
 
-template <int WT, bool USE_MFMA>
+template <int WT, bool USE_MFMA, int PART>
 __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors(const DevParams P, const MlpPlan plan,
                                                                 const float* __restrict__ blob,
                                                                 const float* __restrict__ X, const float* __restrict__ U,
@@ -41,7 +44,11 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors(const DevParams 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // width <= 64: all five inputs in one pass (21 slabs of 4 WT registers); width 128: four passes over input triples
     constexpr bool kSingle = WT <= 4;
-    MlpEngine<kSingle ? 21 : 10, WT, USE_MFMA, false, true> eng(plan, blob, smem);
+    // width 128: two triples here + the bipartite pass in a second launch (PART 1).  (Not instantiated for the VALU
+    // validation flavour: tools/gen_nn_units.py.)
+    constexpr bool kTwoPart = !kSingle;
+    static_assert(PART == 0 || (PART == 1 && kTwoPart), "PART 1 (the bipartite pass) exists for width 128 only");
+    MlpEngine<kSingle ? 21 : (PART == 1 ? 9 : 10), WT, USE_MFMA, false, true> eng(plan, blob, smem);
     eng.load_weights();
     const WaveUnit w(n, blk);
     float x0[13], u[7];
@@ -88,11 +95,26 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors(const DevParams 
                     }
                 }
             }
+        } else if constexpr (PART == 1) {
+            eng.set_quad(0, 1, 3, 4);
+            float yy[6], D[6][8];  // D[k] = d/dz_0, 1, 3, 4 (PART 0 stores those), then the cross pairs 03, 04, 13, 14
+            eng.forward(z, yy, D);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) prov.y[k] = yy[k];
+            if (w.live && w.g == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    o[(long)(36 + k * 15 + pair_index(0, 3)) * blk] = D[k][4];
+                    o[(long)(36 + k * 15 + pair_index(0, 4)) * blk] = D[k][5];
+                    o[(long)(36 + k * 15 + pair_index(1, 3)) * blk] = D[k][6];
+                    o[(long)(36 + k * 15 + pair_index(1, 4)) * blk] = D[k][7];
+                }
+            }
         } else {
 #pragma nounroll
-        for (int pass = 0; pass < 4; ++pass) {
-            // triples {0,1,2} {0,3,4} {1,3,4} {2,3,4}
-            const int tp = pass < 2 ? 0 : pass - 1, tq = pass == 0 ? 1 : 3, tr = pass == 0 ? 2 : 4;
+        for (int pass = 0; pass < 2; ++pass) {
+            // triples {0,1,2} {2,3,4}; the cross pairs 03 04 13 14 come from PART 1
+            const int tp = pass == 0 ? 0 : 2, tq = pass == 0 ? 1 : 3, tr = pass == 0 ? 2 : 4;
             eng.set_triple(tp, tq, tr);
             float yy[6], D[6][9];
             eng.forward(z, yy, D);

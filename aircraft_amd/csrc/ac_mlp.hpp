@@ -96,27 +96,31 @@ AC_DI void lds_dma_copy(const float* __restrict__ gsrc, char* lds_dst, int bytes
 // The input triple of the second-order mode lives in a base class that is EMPTY for every other engine: a member the
 // step kernels never read still moved hipcc's register allocation of k_nn_step_sens (scratch 228 -> 264 B, -1.2 %).
 template <bool ON> struct TripleHolder {
-    int tri_p = 0, tri_q = 1, tri_r = 2;
+    int tri_p = 0, tri_q = 1, tri_r = 2, tri_t = 3;
     AC_DI void set_triple(int p, int q, int r) { tri_p = p; tri_q = q; tri_r = r; }
-    AC_DI int tri(int i) const { return i == 0 ? tri_p : i == 1 ? tri_q : tri_r; }
+    AC_DI void set_quad(int p, int q, int r, int t) { tri_p = p; tri_q = q; tri_r = r; tri_t = t; }
+    AC_DI int tri(int i) const { return i == 0 ? tri_p : i == 1 ? tri_q : i == 2 ? tri_r : tri_t; }
 };
 template <> struct TripleHolder<false> {
     AC_DI int tri(int) const { return 0; }
 };
 
 template <int NSLAB, int WT, bool USE_MFMA, bool TANGENT = (NSLAB == 6), bool SECOND = false, int TOFF = 0>
-struct MlpEngine : TripleHolder<SECOND && NSLAB == 10> {
-    using TripleHolder<SECOND && NSLAB == 10>::tri;
+struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
+    using TripleHolder<SECOND && NSLAB <= 10>::tri;
     static_assert(!TANGENT || (NSLAB >= 2 && NSLAB <= 6 && TOFF + NSLAB - 1 <= 5), "tangent mode = value + a range of the 5 input tangents");
     static constexpr int kTangents = TANGENT ? NSLAB - 1 : 0;
     // second-order mode over K inputs (a triple (p, q, r) set with set_triple(), NSLAB = 10; or all five, NSLAB = 21):
     // slab 0 value; 1..K d/dz_i; K+1..2K d2/dz_i2; then d2/dz_i dz_j for the pairs i < j in lexicographic order
     // (K = 3: 7-9 = pq, pr, qr).  NSLAB = 1 + K + K (K + 1) / 2.
-    static_assert(!SECOND || ((NSLAB == 10 || NSLAB == 21) && !TANGENT), "second-order mode = value + K first-order + K (K + 1) / 2 second-order slabs, K = 3 or 5");
-    static constexpr int kFirstOrder = !SECOND ? 0 : (NSLAB == 10 ? 3 : 5);  // = K: slabs 1..K are first-order
+    // Bipartite layout (NSLAB = 9, inputs (p, q | r, t) set with set_quad()): slab 0 value; 1-4 d/dz_p, q, r, t; 5-8 the four
+    // cross derivatives pr, pt, qr, qt — the pairs between two input groups whose own pairs other passes cover.
+    static_assert(!SECOND || ((NSLAB == 9 || NSLAB == 10 || NSLAB == 21) && !TANGENT), "second-order mode: 9 (bipartite), 10 (triple) or 21 (all five inputs) slabs");
+    static constexpr int kFirstOrder = !SECOND ? 0 : (NSLAB == 10 ? 3 : NSLAB == 9 ? 4 : 5);  // slabs 1..K are first-order
     // first-order slabs (1-based input positions) whose product the second-order slab s differentiates
     AC_DI static constexpr int second_a(int s) {
         constexpr int K = kFirstOrder;
+        if (NSLAB == 9) return s < 7 ? 1 : 2;
         if (s <= 2 * K) return s - K;
         int m = s - 2 * K - 1;
         for (int i = 1; i < K; ++i) { if (m < K - i) return i; m -= K - i; }
@@ -124,12 +128,13 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB == 10> {
     }
     AC_DI static constexpr int second_b(int s) {
         constexpr int K = kFirstOrder;
+        if (NSLAB == 9) return (s & 1) ? 3 : 4;
         if (s <= 2 * K) return s - K;
         int m = s - 2 * K - 1;
         for (int i = 1; i < K; ++i) { if (m < K - i) return i + 1 + m; m -= K - i; }
         return K;
     }
-    AC_DI int input_of(int i) const { if constexpr (NSLAB == 10) return tri(i); else return i; }
+    AC_DI int input_of(int i) const { if constexpr (NSLAB <= 10) return tri(i); else return i; }
     static constexpr bool kTangent = TANGENT;
     static constexpr bool kDeriv = TANGENT || SECOND;  // slabs > 0 are derivative slabs (no bias, chain-rule epilogue)
     static constexpr int CH = WT < 4 ? WT : 4;  // output tiles computed together (independent accumulators)

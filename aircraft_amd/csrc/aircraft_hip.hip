@@ -641,13 +641,17 @@ static int hess_impl(ac_handle* h, const float* X, const float* U, float dt, con
         const int grid_t = (int)((n + 63) / 64);
         const int lds = h->plan.lds_total;
         bool launched = false;
-        AC_NN_CASE(2, true, (k_nn_stage_tensors<2, true>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
-        AC_NN_CASE(4, true, (k_nn_stage_tensors<4, true>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
-        AC_NN_CASE(8, true, (k_nn_stage_tensors<8, true>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
-        AC_NN_CASE(2, false, (k_nn_stage_tensors<2, false>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
-        AC_NN_CASE(4, false, (k_nn_stage_tensors<4, false>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
-        AC_NN_CASE(8, false, (k_nn_stage_tensors<8, false>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
-        if (!launched) return AC_ERR_UNSUPPORTED;
+        AC_NN_CASE(2, true, (k_nn_stage_tensors<2, true, 0>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
+        AC_NN_CASE(4, true, (k_nn_stage_tensors<4, true, 0>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
+        AC_NN_CASE(8, true, (k_nn_stage_tensors<8, true, 0>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
+        AC_NN_CASE(2, false, (k_nn_stage_tensors<2, false, 0>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
+        AC_NN_CASE(4, false, (k_nn_stage_tensors<4, false, 0>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
+        // width 128 on the matrix cores: the cross pairs between inputs {0, 1} and {3, 4} come from a second launch
+        AC_NN_CASE(8, true, (k_nn_stage_tensors<8, true, 1>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
+        if (!launched) {
+            snprintf(g_err, sizeof(g_err), "second-order blocks at width > 64 need the MFMA path (use_mfma = 1)");
+            return AC_ERR_UNSUPPORTED;
+        }
         (void)lds;
         AC_HIP(hipGetLastError());
         launch_hess<AC_MODEL_NN>(h, st, X, U, dt, dt_per_unit, Lam, n, blk, Hout, &grid);
