@@ -138,7 +138,8 @@ int ac_shoot_sens_f32(ac_handle* h, const float* X, const float* U, float dt, co
  * without effect are zero.  All force models (the MLP surrogate evaluates its second-derivative tensor with the MFMA
  * engine into a handle-owned workspace of n*504 floats that grows on demand — the first call of a size allocates, so
  * capture a hipGraph only after one warm-up call or ac_reserve_hess_workspace); substeps == 1 only,
- * AC_ERR_UNSUPPORTED otherwise.  Hout is zero-filled by the call (hipMemsetAsync on `stream`) before the active block is
+ * AC_ERR_UNSUPPORTED otherwise (also for an MLP wider than 64 with use_mfma = 0: the VALU validation flavour has no
+ * second-order instance at that width).  Hout is zero-filled by the call (hipMemsetAsync on `stream`) before the active block is
  * written.  ac_shoot_hess_f32 reads rollout-shaped X [H(+1)][13][B], U [H][7][B], lambda [H][13][B] in place and writes
  * Hout [H][21][21][B]. */
 int ac_step_hess_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit,

@@ -128,3 +128,15 @@ def test_hessian_unsupported_cases_fail_loudly(gpu):
     ac.physical_integration_substeps = 2
     with pytest.raises(AircraftHipError, match="UNSUPPORTED"):
         ac.step_hess(dev(X, gpu), dev(U, gpu), 0.01, dev(lam, gpu))
+
+
+def test_wide_valu_flavour_is_refused(gpu):
+    """Second-order blocks at width > 64 exist on the MFMA path only (include/aircraft_hip.h): the call must fail loudly,
+    not fall back."""
+    import torch
+    from aircraft_amd import AircraftHipError
+    from tests.helpers import make_aircraft
+    ac = make_aircraft("nn", hidden=(128, 128), use_mfma=False)
+    x = torch.zeros((13, 4), device=gpu); x[3] = 30.0; x[9] = 1.0
+    with pytest.raises(AircraftHipError, match="UNSUPPORTED"):
+        ac.step_hess(x, torch.zeros((7, 4), device=gpu), 0.01, torch.ones((13, 4), device=gpu))
