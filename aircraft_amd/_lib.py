@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("AIRCRAFT_HIP_LIB") or os.path.join(_HERE, "libaircraf
 
 AC_OK = 0
 STATUS_NAMES = {0: "AC_OK", -1: "AC_ERR_BAD_ARG", -2: "AC_ERR_HIP", -3: "AC_ERR_UNSUPPORTED",
-                -4: "AC_ERR_NO_MODEL", -5: "AC_ERR_NO_DEVICE"}
+                -4: "AC_ERR_NO_MODEL", -5: "AC_ERR_NO_DEVICE", -6: "AC_ERR_WORKSPACE"}
 MODEL_KINDS = {"default": 0, "linear": 1, "nn": 2, "poly": 3, "quad": 4}
 NUM_STATES = 13
 NUM_CONTROLS = 7
@@ -122,5 +122,5 @@ def load():
 
 def check(rc: int, what: str = "") -> None:
     if rc != AC_OK:
-        msg = load().ac_last_error().decode() if rc == -2 or rc == -3 or rc == -5 else ""
+        msg = load().ac_last_error().decode()  # cleared at the top of every entry point: never a stale text
         raise AircraftHipError(f"{what or 'aircraft_hip call'} failed: {STATUS_NAMES.get(rc, rc)} {msg}".strip())

@@ -121,6 +121,7 @@ class MultipleShooting:
         assert Lam.shape == (H, 13, B) and Lam.is_contiguous() and Lam.dtype == torch.float32
         if out is None:
             out = torch.empty((H, 21, 21, B), device=X.device, dtype=torch.float32)
+        self.system._reserve_hess(H * B)
         _lib.check(lib.ac_shoot_hess_f32(self.system._handle, X.data_ptr(), U.data_ptr(), dts, dtp, Lam.data_ptr(), B, H,
                                          out.data_ptr(), self.system._stream()), "ac_shoot_hess_f32")
         del keep

@@ -85,6 +85,8 @@ class ILQR(MultipleShooting):
                             dV=f(2, B), Xc=f(H + 1, 13, na * B), Uc=f(H, 7, na * B), Jc=f(na * B), J0=f(B))
             if self.hessian_mode == "exact":
                 self._ws.update(Lam=f(H, 13, B), Hz=f(H, 21, 21, B))
+                self.system._sync()
+                self.system._reserve_hess(H * B)  # host-side, once: the solve itself stays allocation-free (capturable)
         return self._ws
 
     def _cstruct(self):

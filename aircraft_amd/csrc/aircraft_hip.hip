@@ -45,6 +45,11 @@ int hip_fail(hipError_t e, const char* what) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
     return AC_ERR_HIP;
 }
+// every non-HIP error return that carries text goes through here, so ac_last_error() never shows a stale message
+int fail(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
 #define AC_HIP(call)                                           \
     do {                                                       \
         hipError_t e_ = (call);                                \
@@ -70,6 +75,10 @@ struct ac_handle {
     size_t hess_ws_floats;
     float* d_track;  // [nseg][3][4] segment cubics (device)
     TrackDev track;
+    // kernels whose dynamic-LDS limit was already raised on this handle's device (hipFuncSetAttribute is not free)
+    const void* lds_fn[48];
+    int lds_bytes_set[48];
+    int n_lds_fn;
     // last launch (profiling aid)
     char last_name[64];
     int last_grid, last_block, last_lds;
@@ -98,11 +107,34 @@ int model_ready(const ac_handle* h) {
     }
 }
 
-template <class K> int set_lds_limit(K kernel, int bytes) {
-    if (bytes > 64 * 1024) AC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+// Raise a kernel's dynamic-LDS limit once per (handle, kernel, size): the attribute is sticky per device, and the call
+// costs a driver round trip that does not belong in front of every launch.
+template <class K> int set_lds_limit(ac_handle* h, K kernel, int bytes) {
+    if (bytes <= 64 * 1024) return AC_OK;
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    for (int i = 0; i < h->n_lds_fn; ++i)
+        if (h->lds_fn[i] == fn) {
+            if (h->lds_bytes_set[i] >= bytes) return AC_OK;
+            AC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+            h->lds_bytes_set[i] = bytes;
+            return AC_OK;
+        }
+    AC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (h->n_lds_fn < 48) { h->lds_fn[h->n_lds_fn] = fn; h->lds_bytes_set[h->n_lds_fn] = bytes; ++h->n_lds_fn; }
     return AC_OK;
 }
+
+// Launch on the handle's device whatever the caller's current device is (a process may hold handles on several GPUs);
+// restores the caller's device on scope exit.  hipSetDevice is host state only: legal during stream capture.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const ac_handle* h) {
+        if (h && hipGetDevice(&prev) == hipSuccess && prev != h->device) switched = hipSetDevice(h->device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+#define AC_ENTER(h) g_err[0] = 0; DeviceGuard dev_guard_(h)
 
 #ifndef AC_HESS_N_POLY
 #define AC_HESS_N_POLY 1
@@ -138,7 +170,7 @@ void launch_hess(ac_handle* h, hipStream_t st, const float* X, const float* U, f
 #define AC_NN_CASE(WT_, MF_, KERNEL_EXPR, GRID, BLOCK, ...)                                          \
     if (h->wt == WT_ && (h->use_mfma != 0) == MF_) {                                                 \
         auto kern = KERNEL_EXPR;                                                                     \
-        int rc_ = set_lds_limit(kern, h->plan.lds_total);                                            \
+        int rc_ = set_lds_limit(h, kern, h->plan.lds_total);                                            \
         if (rc_ != AC_OK) return rc_;                                                                \
         hipLaunchKernelGGL(kern, GRID, BLOCK, h->plan.lds_total, st, h->dp, h->plan, h->d_blob, __VA_ARGS__); \
         launched = true;                                                                             \
@@ -174,7 +206,10 @@ int ac_create(const ac_params* params, ac_handle** out) {
     if (!h) return AC_ERR_BAD_ARG;
     memset(h, 0, sizeof(*h));
     h->dp.p = *params;
-    AC_HIP(hipGetDevice(&h->device));
+    {
+        hipError_t e = hipGetDevice(&h->device);
+        if (e != hipSuccess) { delete h; return hip_fail(e, "hipGetDevice"); }
+    }
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess) h->num_cus = cus;
@@ -191,6 +226,7 @@ int ac_create(const ac_params* params, ac_handle** out) {
 }
 
 int ac_destroy(ac_handle* h) {
+    AC_ENTER(h);
     if (!h) return AC_ERR_BAD_ARG;
     if (h->d_blob) (void)hipFree(h->d_blob);
     if (h->d_track) (void)hipFree(h->d_track);
@@ -225,6 +261,7 @@ int ac_set_poly(ac_handle* h, const float* coef, const float* intercept) {
 int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, const float* const* W,
                const float* const* b, const float* in_mean, const float* in_std, const float* out_mean,
                const float* out_std, int use_mfma) {
+    AC_ENTER(h);
     if (!h || !widths || !act || !W || !b || !in_mean || !in_std || !out_mean || !out_std) return AC_ERR_BAD_ARG;
     if (n_layers < 1 || n_layers > AC_MAX_LAYERS) return AC_ERR_BAD_ARG;
     if (widths[0] != 5 || widths[n_layers] != 6) return AC_ERR_BAD_ARG;
@@ -396,7 +433,7 @@ static int launch_nn_fwd(ac_handle* h, int op, const float* X, const float* U, f
         }
         AC_FWD4_CASE(2) AC_FWD4_CASE(4) AC_FWD4_CASE(8)
 #undef AC_FWD4_CASE
-        if (!launched) return AC_ERR_UNSUPPORTED;
+        if (!launched) return fail(AC_ERR_UNSUPPORTED, "no kernel instance for this MLP width / flavour");
         note_launch(h, op == OP_DERIV ? "k_nn_fwd4<deriv>" : (op == OP_STEP ? "k_nn_fwd4<step>" : "k_nn_fwd4<aero>"), grid4,
                     kBlock, h->plan.lds_total);
         AC_HIP(hipGetLastError());
@@ -411,7 +448,7 @@ static int launch_nn_fwd(ac_handle* h, int op, const float* X, const float* U, f
     AC_FWD_OPS(2, true) AC_FWD_OPS(4, true) AC_FWD_OPS(8, true)
     AC_FWD_OPS(2, false) AC_FWD_OPS(4, false) AC_FWD_OPS(8, false)
 #undef AC_FWD_OPS
-    if (!launched) return AC_ERR_UNSUPPORTED;
+    if (!launched) return fail(AC_ERR_UNSUPPORTED, "no kernel instance for this MLP width / flavour");
     if (n4 == 0)
         note_launch(h, op == OP_DERIV ? "k_nn_fwd<deriv>" : (op == OP_STEP ? "k_nn_fwd<step>" : "k_nn_fwd<aero>"), grid,
                     kBlock, h->plan.lds_total);
@@ -420,6 +457,7 @@ static int launch_nn_fwd(ac_handle* h, int op, const float* X, const float* U, f
 }
 
 int ac_state_derivative_f32(ac_handle* h, const float* X, const float* U, long n, float* Xdot, void* stream) {
+    AC_ENTER(h);
     const long blk = n;
     if (h && n == 0) return AC_OK;  // empty batch: nothing to do (pointers may be NULL)
     if (!h || !X || !U || !Xdot || n < 0) return AC_ERR_BAD_ARG;
@@ -437,6 +475,7 @@ int ac_state_derivative_f32(ac_handle* h, const float* X, const float* U, long n
 
 static int step_impl(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long n, long blk,
                      float* Xn, void* stream) {
+    AC_ENTER(h);
     if (h && n == 0) return AC_OK;
     if (!h || !X || !U || !Xn || n < 0 || blk < 0) return AC_ERR_BAD_ARG;
     int rc = model_ready(h);
@@ -463,6 +502,7 @@ int ac_shoot_step_f32(ac_handle* h, const float* X, const float* U, float dt, co
 }
 
 int ac_aero_f32(ac_handle* h, const float* X, const float* U, long n, float* out, void* stream) {
+    AC_ENTER(h);
     const long blk = n;
     if (h && n == 0) return AC_OK;
     if (!h || !X || !U || !out || n < 0) return AC_ERR_BAD_ARG;
@@ -480,6 +520,7 @@ int ac_aero_f32(ac_handle* h, const float* X, const float* U, long n, float* out
 
 int ac_rollout_f32(ac_handle* h, const float* X0, const float* U, float dt, long B, long H, float* Xout,
                    void* stream) {
+    AC_ENTER(h);
     if (h && B == 0) return AC_OK;
     if (!h || !X0 || !Xout || B < 0 || H < 0 || (H > 0 && !U)) return AC_ERR_BAD_ARG;
     int rc = model_ready(h);
@@ -502,7 +543,7 @@ int ac_rollout_f32(ac_handle* h, const float* X0, const float* U, float dt, long
             AC_REG_CASE(2, 1) AC_REG_CASE(2, 2) AC_REG_CASE(2, 3) AC_REG_CASE(4, 1) AC_REG_CASE(4, 2) AC_REG_CASE(4, 3)
             AC_REG_CASE(8, 1) AC_REG_CASE(8, 2) AC_REG_CASE(8, 3)
 #undef AC_REG_CASE
-            if (!launched) return AC_ERR_UNSUPPORTED;
+            if (!launched) return fail(AC_ERR_UNSUPPORTED, "no kernel instance for this MLP width / flavour");
             note_launch(h, "k_nn_rollout_reg", grid, kBlock, lds);
             AC_HIP(hipGetLastError());
             return AC_OK;
@@ -514,14 +555,14 @@ int ac_rollout_f32(ac_handle* h, const float* X0, const float* U, float dt, long
 #define AC_COOP_CASE(WT_)                                                                                   \
             if (h->wt == WT_) {                                                                             \
                 auto kern = k_nn_rollout_coop<WT_, true>;                                                   \
-                int rc_ = set_lds_limit(kern, lds);                                                         \
+                int rc_ = set_lds_limit(h, kern, lds);                                                         \
                 if (rc_ != AC_OK) return rc_;                                                               \
                 hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->plan, h->d_blob, X0, U, dt, B, H, Xout); \
                 launched = true;                                                                            \
             }
             AC_COOP_CASE(2) AC_COOP_CASE(4) AC_COOP_CASE(8)
 #undef AC_COOP_CASE
-            if (!launched) return AC_ERR_UNSUPPORTED;
+            if (!launched) return fail(AC_ERR_UNSUPPORTED, "no kernel instance for this MLP width / flavour");
             note_launch(h, "k_nn_rollout_coop", grid, kBlock, lds);
             AC_HIP(hipGetLastError());
             return AC_OK;
@@ -533,7 +574,7 @@ int ac_rollout_f32(ac_handle* h, const float* X0, const float* U, float dt, long
         AC_NN_CASE(2, false, (k_nn_rollout<2, false>), grid, kBlock, X0, U, dt, B, H, Xout)
         AC_NN_CASE(4, false, (k_nn_rollout<4, false>), grid, kBlock, X0, U, dt, B, H, Xout)
         AC_NN_CASE(8, false, (k_nn_rollout<8, false>), grid, kBlock, X0, U, dt, B, H, Xout)
-        if (!launched) return AC_ERR_UNSUPPORTED;
+        if (!launched) return fail(AC_ERR_UNSUPPORTED, "no kernel instance for this MLP width / flavour");
         note_launch(h, "k_nn_rollout", grid, kBlock, h->plan.lds_total);
         AC_HIP(hipGetLastError());
         return AC_OK;
@@ -547,6 +588,7 @@ int ac_rollout_f32(ac_handle* h, const float* X0, const float* U, float dt, long
 
 static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long n, long blk,
                      float* Xn, float* A, float* Bm, float* c, void* stream) {
+    AC_ENTER(h);
     if (h && n == 0) return AC_OK;
     if (!h || !X || !U || !Xn || !A || !Bm || n < 0 || blk < 0) return AC_ERR_BAD_ARG;
     int rc = model_ready(h);
@@ -573,7 +615,7 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
             AC_NN_CASE(2, false, (k_nn_step_sens<2, false>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
             AC_NN_CASE(4, false, (k_nn_step_sens<4, false>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
             AC_NN_CASE(8, false, (k_nn_step_sens<8, false>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
-            if (!launched) return AC_ERR_UNSUPPORTED;
+            if (!launched) return fail(AC_ERR_UNSUPPORTED, "no kernel instance for this MLP width / flavour");
             note_launch(h, "k_nn_step_sens", grid, kBlock, h->plan.lds_total);
             AC_HIP(hipGetLastError());
         }
@@ -584,7 +626,7 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
 #define AC_PAIR_CASE(WT_)                                                                                              \
             if (h->wt == WT_) {                                                                                        \
                 auto kern = k_nn_step_sens_pair<WT_>;                                                                  \
-                int rc_ = set_lds_limit(kern, lds_p);                                                                  \
+                int rc_ = set_lds_limit(h, kern, lds_p);                                                                  \
                 if (rc_ != AC_OK) return rc_;                                                                          \
                 hipLaunchKernelGGL(kern, grid_p, kBlock, lds_p, st, h->dp, h->plan, h->d_blob, X, U, dt, dt_per_unit, n, \
                                    blk, Xn, A, Bm, c, n_main);                                                          \
@@ -592,7 +634,7 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
             }
             AC_PAIR_CASE(2) AC_PAIR_CASE(4) AC_PAIR_CASE(8)
 #undef AC_PAIR_CASE
-            if (!launched) return AC_ERR_UNSUPPORTED;
+            if (!launched) return fail(AC_ERR_UNSUPPORTED, "no kernel instance for this MLP width / flavour");
             if (n_main == 0) note_launch(h, "k_nn_step_sens_pair", grid_p, kBlock, lds_p);
             AC_HIP(hipGetLastError());
         }
@@ -622,22 +664,23 @@ int ac_shoot_sens_f32(ac_handle* h, const float* X, const float* U, float dt, co
 // ---- second-order step sensitivities ---------------------------------------------------------------
 static int hess_impl(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, const float* Lam,
                      long n, long blk, float* Hout, void* stream) {
+    AC_ENTER(h);
     if (h && n == 0) return AC_OK;
     if (!h || !X || !U || !Lam || !Hout || n < 0 || blk <= 0) return AC_ERR_BAD_ARG;
-    if (h->dp.p.substeps != 1) return AC_ERR_UNSUPPORTED;
+    if (h->dp.p.substeps != 1) return fail(AC_ERR_UNSUPPORTED, "second-order blocks: substeps > 1 not supported");
     int rc = model_ready(h);
     if (rc != AC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    AC_HIP(hipMemsetAsync(Hout, 0, (size_t)n * 441 * sizeof(float), st));
     int grid = 0;
+    if (h->dp.p.model_kind == AC_MODEL_NN && (size_t)n * kStageFloats > h->hess_ws_floats)
+        return fail(AC_ERR_WORKSPACE, "second-order workspace too small: call ac_reserve_hess_workspace(h, n) first");
+    AC_HIP(hipMemsetAsync(Hout, 0, (size_t)n * 441 * sizeof(float), st));
     if (h->dp.p.model_kind == AC_MODEL_NN) {
         // stage tensors (y, J, T at the four RK4 stage points) into the handle's workspace, then the same second-order
-        // kernel with the tensor provider.  The workspace grows on demand: the first call of a given size allocates.
-        if ((size_t)n * kStageFloats > h->hess_ws_floats) {
-            AC_HIP(hipStreamSynchronize(st));
-            rc = ac_reserve_hess_workspace(h, n);
-            if (rc != AC_OK) return rc;
-        }
+        // kernel with the tensor provider.  The workspace is sized by ac_reserve_hess_workspace (a host-side call that may
+        // allocate); a compute call never allocates, frees or synchronises.
+        if ((size_t)n * kStageFloats > h->hess_ws_floats)
+            return fail(AC_ERR_WORKSPACE, "second-order workspace too small: call ac_reserve_hess_workspace(h, n) first");
         const int grid_t = (int)((n + 63) / 64);
         const int lds = h->plan.lds_total;
         bool launched = false;
@@ -671,6 +714,7 @@ static int hess_impl(ac_handle* h, const float* X, const float* U, float dt, con
 }
 
 int ac_reserve_hess_workspace(ac_handle* h, long n) {
+    AC_ENTER(h);
     if (!h || n < 0) return AC_ERR_BAD_ARG;
     const size_t need = (size_t)n * kStageFloats;
     if (need <= h->hess_ws_floats) return AC_OK;
@@ -694,6 +738,7 @@ int ac_shoot_hess_f32(ac_handle* h, const float* X, const float* U, float dt, co
 
 int ac_traj_cost_f32(ac_handle* h, const float* X, long B, long H, const float* goal3, float w_track, float w_goal,
                      float* cost, void* stream) {
+    AC_ENTER(h);
     if (h && B == 0) return AC_OK;
     if (!h || !X || !goal3 || !cost || B < 0 || H < 0) return AC_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -726,6 +771,7 @@ int ac_ilqr_backward_node_f32(ac_handle* h, const ac_ilqr_cost* cost, const floa
 int ac_ilqr_costate_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* node_q, const float* node_xref,
                         const float* node_glin, const float* X, const float* A, long B, long H, float* Lam,
                         void* stream) {
+    AC_ENTER(h);
     if (h && B == 0) return AC_OK;
     if (!h || !cost || !X || !A || !Lam || B < 0 || H < 1) return AC_ERR_BAD_ARG;
     if ((node_q || node_xref || node_glin) && !(node_q && node_xref && node_glin)) return AC_ERR_BAD_ARG;
@@ -741,6 +787,7 @@ int ac_ilqr_costate_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* nod
 int ac_ilqr_backward_newton_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* node_q, const float* node_xref,
                                 const float* node_glin, const float* Hz, const float* X, const float* U, const float* A,
                                 const float* Bm, long B, long H, float* K, float* kff, float* dV, void* stream) {
+    AC_ENTER(h);
     if (h && B == 0) return AC_OK;
     if (!h || !cost || !X || !U || !A || !Bm || !K || !kff || !dV || B < 0 || H < 1) return AC_ERR_BAD_ARG;
     if ((node_q || node_xref || node_glin) && !(node_q && node_xref && node_glin)) return AC_ERR_BAD_ARG;
@@ -767,6 +814,7 @@ int ac_ilqr_cost_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* X, con
 int ac_ilqr_cost_node_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* node_q, const float* node_xref,
                           const float* node_glin, long Bn, const float* X, const float* U, long B, long H, float* out,
                           void* stream) {
+    AC_ENTER(h);
     if (h && B == 0) return AC_OK;
     if (!h || !cost || !X || !U || !out || B < 0 || H < 1) return AC_ERR_BAD_ARG;
     if ((node_q || node_xref || node_glin) && !(node_q && node_xref && node_glin && Bn > 0)) return AC_ERR_BAD_ARG;
@@ -783,10 +831,16 @@ int ac_ilqr_cost_node_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* n
 // ---- track + progress terms -------------------------------------------------------------------------
 int ac_set_track(ac_handle* h, int n_segments, const float* coef, float length) {
     if (!h || !coef || n_segments < 1 || !(length > 0.f)) return AC_ERR_BAD_ARG;
+    AC_ENTER(h);
     if (h->d_track) { (void)hipFree(h->d_track); h->d_track = nullptr; }
+    memset(&h->track, 0, sizeof(h->track));  // no dangling device pointer if anything below fails
     const size_t bytes = (size_t)n_segments * 12 * sizeof(float);
-    AC_HIP(hipMalloc((void**)&h->d_track, bytes));
-    AC_HIP(hipMemcpy(h->d_track, coef, bytes, hipMemcpyHostToDevice));
+    {
+        hipError_t e = hipMalloc((void**)&h->d_track, bytes);
+        if (e != hipSuccess) { h->d_track = nullptr; return hip_fail(e, "hipMalloc(track)"); }
+        e = hipMemcpy(h->d_track, coef, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(h->d_track); h->d_track = nullptr; return hip_fail(e, "hipMemcpy(track)"); }
+    }
     h->track.coef = h->d_track;
     h->track.nseg = n_segments;
     h->track.inv_length = 1.f / length;
@@ -796,6 +850,7 @@ int ac_set_track(ac_handle* h, int n_segments, const float* coef, float length) 
 }
 
 int ac_track_eval_f32(ac_handle* h, const float* s, long n, float* pos, float* tangent, void* stream) {
+    AC_ENTER(h);
     if (h && n == 0) return AC_OK;
     if (!h || !s || !pos || !tangent || n < 0) return AC_ERR_BAD_ARG;
     if (!h->d_track) return AC_ERR_NO_MODEL;
@@ -816,6 +871,7 @@ static MhttWeights to_dev_weights(const ac_mhtt_weights* w) {
 int ac_track_progress_f32(ac_handle* h, const ac_mhtt_weights* weights, const float* X, const float* s0, float dt,
                           long B, long H, int mode, float* S, float* s_dot, float* track_err, float* node_q,
                           float* node_xref, float* node_glin, void* stream) {
+    AC_ENTER(h);
     if (h && B == 0) return AC_OK;
     if (!h || !X || !s0 || !S || B < 0 || H < 1 || (mode != 0 && mode != 1)) return AC_ERR_BAD_ARG;
     const bool any = node_q || node_xref || node_glin;
@@ -831,6 +887,7 @@ int ac_track_progress_f32(ac_handle* h, const ac_mhtt_weights* weights, const fl
 
 int ac_mhtt_loss_f32(ac_handle* h, const ac_mhtt_weights* weights, const float* X, const float* U, const float* S,
                      long B, long H, float* J, void* stream) {
+    AC_ENTER(h);
     if (h && B == 0) return AC_OK;
     if (!h || !weights || !X || !U || !S || !J || B < 0 || H < 1) return AC_ERR_BAD_ARG;
     if (!h->d_track) return AC_ERR_NO_MODEL;
@@ -845,6 +902,7 @@ int ac_mhtt_loss_f32(ac_handle* h, const ac_mhtt_weights* weights, const float* 
 int ac_rollout_policy_f32(ac_handle* h, const ac_ilqr_cost* limits, const float* X0, const float* Xnom, const float* U,
                           const float* K, const float* kff, const float* alphas, int n_alpha, float dt, long B, long H,
                           float* Xout, float* Uout, void* stream) {
+    AC_ENTER(h);
     if (h && B == 0) return AC_OK;
     if (!h || !limits || !X0 || !Xnom || !U || !K || !kff || !alphas || !Xout || !Uout || B < 0 || H < 1) return AC_ERR_BAD_ARG;
     if (n_alpha < 1 || n_alpha > 8) return AC_ERR_BAD_ARG;
@@ -876,7 +934,7 @@ int ac_rollout_policy_f32(ac_handle* h, const ac_ilqr_cost* limits, const float*
             AC_POLREG_CASE(2, 1) AC_POLREG_CASE(2, 2) AC_POLREG_CASE(2, 3) AC_POLREG_CASE(4, 1) AC_POLREG_CASE(4, 2)
             AC_POLREG_CASE(4, 3) AC_POLREG_CASE(8, 1) AC_POLREG_CASE(8, 2) AC_POLREG_CASE(8, 3)
 #undef AC_POLREG_CASE
-            if (!launched) return AC_ERR_UNSUPPORTED;
+            if (!launched) return fail(AC_ERR_UNSUPPORTED, "no kernel instance for this MLP width / flavour");
             note_launch(h, "k_nn_rollout_policy_reg", grid, kBlock, ldsr);
             AC_HIP(hipGetLastError());
             return AC_OK;
@@ -885,14 +943,14 @@ int ac_rollout_policy_f32(ac_handle* h, const ac_ilqr_cost* limits, const float*
 #define AC_POL_CASE(WT_)                                                                                        \
         if (h->wt == WT_) {                                                                                     \
             auto kern = k_nn_rollout_policy_coop<WT_, true>;                                                    \
-            int rc_ = set_lds_limit(kern, lds);                                                                 \
+            int rc_ = set_lds_limit(h, kern, lds);                                                                 \
             if (rc_ != AC_OK) return rc_;                                                                       \
             hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->plan, h->d_blob, pol, X0, dt, Bout, H, Xout, Uout); \
             launched = true;                                                                                    \
         }
         AC_POL_CASE(2) AC_POL_CASE(4) AC_POL_CASE(8)
 #undef AC_POL_CASE
-        if (!launched) return AC_ERR_UNSUPPORTED;
+        if (!launched) return fail(AC_ERR_UNSUPPORTED, "no kernel instance for this MLP width / flavour");
         note_launch(h, "k_nn_rollout_policy_coop", grid, kBlock, lds);
         AC_HIP(hipGetLastError());
         return AC_OK;

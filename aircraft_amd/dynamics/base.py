@@ -298,11 +298,24 @@ class SixDOF(ABC):
         dts, dtp, keep = self._dt_args(dt, n)
         if out is None:
             out = torch.empty((21, 21, n), device=X.device, dtype=torch.float32)
+        self._reserve_hess(n)
         _lib.check(lib.ac_step_hess_f32(self._handle, X.data_ptr(), U.data_ptr(), dts, dtp, L.data_ptr(), n,
                                         out.data_ptr(), self._stream()), "ac_step_hess_f32")
         del keep
         res = out.cpu().numpy().astype(np.float64) if npx else out
         return res[..., 0] if vec else res
+
+    def _reserve_hess(self, n: int) -> None:
+        """Size the handle's second-order workspace for n units.  Host-side and idempotent (the library only grows
+        it); the compute calls themselves never allocate, so call this before capturing a hipGraph."""
+        n = int(n)
+        if n > getattr(self, "_hess_reserved", 0):
+            torch = _torch()
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.AircraftHipError("second-order workspace must be reserved before stream capture: "
+                                            "call system._reserve_hess(n) (ac_reserve_hess_workspace) first")
+            _lib.check(_lib.load().ac_reserve_hess_workspace(self._handle, n), "ac_reserve_hess_workspace")
+            self._hess_reserved = n
 
     # ---- getters (reference dynamics/base.py:147-278, aircraft.py:255-330) ------------------------
     def _aero(self, x, u):

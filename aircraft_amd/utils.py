@@ -151,16 +151,27 @@ class _Inert:
         self.__dict__["_state"] = st
 
 
+# The only numpy globals an array / scalar pickle needs (numpy >= 2 writes numpy._core, older files numpy.core).
+_NUMPY_PICKLE_GLOBALS = {
+    ("numpy._core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "_reconstruct"),
+    ("numpy._core.multiarray", "scalar"), ("numpy.core.multiarray", "scalar"),
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+}
+
+
 class _RestrictedUnpickler(pickle.Unpickler):
     """The reference's fitted_models_casadi.pkl holds sklearn and casadi objects; only the numpy
-    coefficient arrays are needed, so everything else unpickles to an inert stub and nothing executes."""
+    coefficient arrays are needed.  Exactly the six numpy reconstructors an array pickle uses are
+    allowed — NOT the `numpy` package as a whole (numpy.testing._private.utils.runstring, numpy.load
+    with allow_pickle and others would execute code) — sklearn / casadi classes unpickle to inert
+    stubs, and every other global is refused."""
 
     def find_class(self, module, name):
-        root = module.split(".")[0]
-        if root == "numpy":
+        if (module, name) in _NUMPY_PICKLE_GLOBALS:
             import importlib
 
             return getattr(importlib.import_module(module), name)
+        root = module.split(".")[0]
         if root in ("sklearn", "casadi"):
             return type(name, (_Inert,), {})
         raise pickle.UnpicklingError(f"blocked global {module}.{name}")

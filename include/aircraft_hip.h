@@ -46,7 +46,8 @@ typedef enum ac_status {
     AC_ERR_HIP = -2,           /* a HIP runtime call failed; see ac_last_error() */
     AC_ERR_UNSUPPORTED = -3,   /* e.g. MLP wider than AC_MAX_WIDTH */
     AC_ERR_NO_MODEL = -4,      /* model_kind needs data that was never set */
-    AC_ERR_NO_DEVICE = -5      /* no gfx950 device visible */
+    AC_ERR_NO_DEVICE = -5,     /* no gfx950 device visible */
+    AC_ERR_WORKSPACE = -6      /* a handle-owned workspace is too small: call the matching ac_reserve_* first */
 } ac_status;
 
 /* Registry keys of COEFF_MODEL_REGISTRY, dynamics/coefficient_models.py:32-37 */
@@ -135,17 +136,20 @@ int ac_shoot_sens_f32(ac_handle* h, const float* X, const float* U, float dt, co
  * block the defect rows x_{k+1} - F(x_k, u_k, dt_k) (control/base.py:279-280) contribute to IPOPT's `nlp_hess_l`
  * (the reference's largest time sink, todo.md:102).  lambda [13][n] (device) are the multipliers of the 13 rows of F.
  * Exact second-order forward mode of the same fp32 arithmetic as ac_step_f32.  Rows/columns of p (0-2) and of controls
- * without effect are zero.  All force models (the MLP surrogate evaluates its second-derivative tensor with the MFMA
- * engine into a handle-owned workspace of n*504 floats that grows on demand — the first call of a size allocates, so
- * capture a hipGraph only after one warm-up call or ac_reserve_hess_workspace); substeps == 1 only,
+ * without effect are zero.  All force models.  The MLP surrogate evaluates its second-derivative tensor with the MFMA
+ * engine into a handle-owned workspace of n*504 floats: size it once with ac_reserve_hess_workspace(h, n_max) — a
+ * host-side call that may allocate — BEFORE the first compute call (and before capturing a hipGraph); the compute calls
+ * themselves never allocate, free or synchronise and return AC_ERR_WORKSPACE when the workspace is too small.  The
+ * workspace is one buffer per handle: second-order calls of one handle must be ordered on one stream (or use one handle
+ * per stream).  substeps == 1 only,
  * AC_ERR_UNSUPPORTED otherwise (also for an MLP wider than 64 with use_mfma = 0: the VALU validation flavour has no
  * second-order instance at that width).  Hout is zero-filled by the call (hipMemsetAsync on `stream`) before the active block is
  * written.  ac_shoot_hess_f32 reads rollout-shaped X [H(+1)][13][B], U [H][7][B], lambda [H][13][B] in place and writes
  * Hout [H][21][21][B]. */
 int ac_step_hess_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit,
                      const float* lambda, long n, float* Hout, void* stream);
-/* Size the MLP path's workspace for n units ahead of time (e.g. before capturing a hipGraph); a no-op for the other
- * models' needs and when it is already large enough. */
+/* Size the MLP path's workspace for n units (hipFree + hipMalloc when it must grow: implicit device synchronisation, not
+ * capturable); a no-op for the other models and when it is already large enough. */
 int ac_reserve_hess_workspace(ac_handle* h, long n);
 int ac_shoot_hess_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit,
                       const float* lambda, long B, long H, float* Hout, void* stream);

@@ -193,3 +193,14 @@ def num_threads():
 
 def set_num_threads(n):
     lib().oracle_set_num_threads(int(n))
+
+
+def for_aircraft(ac) -> "Oracle":
+    """The float64 oracle for the same airframe / coefficient model / options as the product object `ac`
+    (an aircraft_amd.Aircraft or Quadrotor).  Used by tests/, smoke() and bench.py's cpu_baseline leg."""
+    md = ac.coefficient_model.oracle_data() if hasattr(ac, "coefficient_model") else None
+    if ac.model_kind == "nn":
+        md = {k: ([np.asarray(a, dtype=np.float64) for a in v] if k in ("weights", "biases") else v)
+              for k, v in md.items()}
+    return Oracle(ac.airframe_dict(), ac.model_kind, md, substeps=ac.physical_integration_substeps,
+                  normalise=ac.normalise, stall_scaling=ac.stall_scaling, epsilon=ac.epsilon, gravity=ac.gravity)

@@ -53,15 +53,10 @@ def make_aircraft(model="default", *, hidden=None, substeps=1, normalise=False, 
 
 
 def make_oracle(ac: Aircraft):
-    """The float64 oracle for the same airframe / model / options as `ac`."""
-    from oracle import Oracle
+    """The float64 oracle for the same airframe / model / options as `ac` (oracle/oracle.py::for_aircraft)."""
+    from oracle import for_aircraft
 
-    md = ac.coefficient_model.oracle_data()
-    if ac.model_kind == "nn":
-        md = {k: ([np.asarray(a, dtype=np.float64) for a in v] if k in ("weights", "biases") else v)
-              for k, v in md.items()}
-    return Oracle(ac.airframe_dict(), ac.model_kind, md, substeps=ac.physical_integration_substeps,
-                  normalise=ac.normalise, stall_scaling=ac.stall_scaling, epsilon=ac.epsilon, gravity=ac.gravity)
+    return for_aircraft(ac)
 
 
 BLOCKS = {"p": slice(0, 3), "v": slice(3, 6), "q": slice(6, 10), "w": slice(10, 13)}

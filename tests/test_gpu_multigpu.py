@@ -1,0 +1,126 @@
+"""GPU side of the multi-GPU layer: the K6 cost / top-K kernel against the torch formula, the record
+packing on device tensors, and a 2-rank rehearsal of bench.py on ONE GPU (both ranks on cuda:0, collectives over gloo)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.helpers import ROOT, make_aircraft, near_trim_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_cost(X, goal, w_track, w_goal):
+    import torch
+
+    d = X[:, 0:3, :].double() - torch.as_tensor(goal, dtype=torch.float64, device=X.device)[None, :, None]
+    sq = (d * d).sum(dim=1)  # (H+1, B)
+    return w_track * sq.sum(dim=0) + w_goal * sq[-1]
+
+
+@pytest.mark.parametrize("B,H", [(1, 1), (37, 5), (300, 50), (2048, 100)])
+def test_traj_cost_kernel_matches_the_torch_formula(gpu, B, H):
+    """ac_traj_cost_f32 (k_traj_cost) on a real rollout: cost[b] = w_track sum_k |p_k - g|^2 + w_goal |p_H - g|^2."""
+    import torch
+
+    from aircraft_amd.distributed import trajectory_cost
+
+    ac = make_aircraft("poly", normalise=True)
+    X0, U = near_trim_problem(B, H, seed=5)  # trajectories that stay finite (random ones tumble and overflow)
+    X = ac.rollout(torch.from_numpy(X0).float().to(gpu), torch.from_numpy(U).float().to(gpu), 0.01)
+    goal = (150.0, 10.0, -190.0)
+    for wt, wg in ((1.0, 10.0), (0.25, 0.0), (0.0, 3.0)):
+        cost = trajectory_cost(ac, X, goal, wt, wg)
+        want = _torch_cost(X, goal, wt, wg)
+        assert cost.shape == (B,) and cost.dtype == torch.float32 and torch.isfinite(want).all()
+        rel = ((cost.double() - want).abs() / want.abs().clamp_min(1e-12)).max().item()
+        assert rel < 2e-6, rel  # fp32 running sum of H+1 positive terms vs float64
+
+
+def test_traj_cost_status_codes_and_nan(gpu):
+    import ctypes as C
+
+    import torch
+
+    from aircraft_amd import _lib
+
+    lib = _lib.load()
+    ac = make_aircraft("default")
+    ac._sync()
+    h, st = ac._handle, ac._stream()
+    X = torch.zeros((4, 13, 8), device=gpu)
+    X[2, 1, 3] = float("nan")
+    cost = torch.zeros(8, device=gpu)
+    g = (C.c_float * 3)(0, 0, 0)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    assert lib.ac_traj_cost_f32(h, p(X), 8, 3, g, C.c_float(1), C.c_float(1), p(cost), st) == 0
+    torch.cuda.synchronize()
+    c = cost.cpu().numpy()
+    assert np.isnan(c[3]) and np.isfinite(np.delete(c, 3)).all()  # NaNs propagate, per instance
+    assert lib.ac_traj_cost_f32(h, None, 8, 3, g, C.c_float(1), C.c_float(1), p(cost), st) == -1
+    assert lib.ac_traj_cost_f32(h, p(X), -1, 3, g, C.c_float(1), C.c_float(1), p(cost), st) == -1
+    assert lib.ac_traj_cost_f32(h, None, 0, 3, None, C.c_float(1), C.c_float(1), None, st) == 0  # empty batch
+
+
+def test_gather_best_on_device_records(gpu):
+    """cost kernel -> top-K -> record packing on device tensors (single process: the gather is the identity)."""
+    import torch
+
+    from aircraft_amd.distributed import gather_best, pack_records, trajectory_cost, unpack_records
+
+    ac = make_aircraft("poly", normalise=True)
+    B, H, k = 512, 20, 4
+    X0, U = near_trim_problem(B, H, seed=9)
+    Ud = torch.from_numpy(U).float().to(gpu)
+    X = ac.rollout(torch.from_numpy(X0).float().to(gpu), Ud, 0.01)
+    goal = torch.tensor([150.0, 10.0, -190.0], device=gpu)
+    cost = trajectory_cost(ac, X, goal)
+    rec = pack_records(cost, X, Ud, k)
+    assert rec.is_cuda and rec.shape == (k, 1 + (H + 1) * 13 + H * 7)
+    c, Xb, Ub = unpack_records(rec, H)
+    order = torch.argsort(_torch_cost(X, goal.tolist(), 1.0, 10.0))[:k]
+    assert torch.equal(torch.argsort(cost)[:k], order)
+    for i, b in enumerate(order.tolist()):
+        assert torch.equal(Xb[i], X[:, :, b]) and torch.equal(Ub[i], Ud[:, :, b]) and c[i] == cost[b]
+    c2, Xb2, Ub2 = gather_best(X, Ud, goal, k=k, system=ac)
+    assert torch.equal(c2, c) and torch.equal(Xb2, Xb) and torch.equal(Ub2, Ub)
+
+
+def _run_bench(extra, env_extra, timeout=600):
+    env = dict(os.environ)
+    env.update(env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "512",
+                        "--no-cpu-baseline", "--no-extras", *extra], env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    return r
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu(gpu):
+    """`python bench.py --gpus 2` with no launcher starts two fresh ranks itself (here both on cuda:0, gloo collectives)
+    and reports n_gpus = ranks_seen = 2 with weak- and strong-scaled figures; the N = 1 line has the same keys."""
+    r = _run_bench(["--gpus", "2"], {"AIRCRAFT_BENCH_ONE_GPU": "1", "AIRCRAFT_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["scaling"] == "weak"
+    assert res["config"]["units_per_step"] == 2 * 512 * 50 and res["config"]["batch_per_gpu"] == 512
+    s = res["strong"]
+    assert s["scaling"] == "strong" and s["batch_total"] == 512 and s["batch_per_gpu"] == 256
+    assert s["units_per_step"] == 512 * 50 and s["value"] > 0 and res["value"] > 0
+    assert res["roofline"]["frac"] > 0 and "cpu_baseline" not in res  # baseline leg is rank-0-at-N=1 only
+
+
+def test_bench_refuses_a_mislabelled_run(gpu):
+    """One rank launched as if it were one of two (--gpus 2 under WORLD_SIZE=1) must fail, not print n_gpus 1."""
+    r = _run_bench(["--gpus", "2"], {})
+    # without the rehearsal switches a one-GPU box cannot host two ranks: every rank exits 3, the parent relays it
+    assert r.returncode != 0 and "need" in r.stderr
+    env = {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-extras"], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()

@@ -143,6 +143,40 @@ def test_restricted_unpickler_blocks_code_execution(tmp_path):
         load_poly(str(p))
 
 
+def test_restricted_unpickler_blocks_numpy_gadgets(tmp_path):
+    """Only the six numpy reconstructors are allowed, not the numpy package: numpy.testing's runstring and
+    numpy.load(allow_pickle=True) would otherwise execute code from a crafted .pkl (round-1 advisor finding)."""
+    import pickle
+
+    import numpy.testing._private.utils as ntu
+
+    from aircraft_amd.utils import load_poly
+
+    marker = tmp_path / "pwned"
+
+    class RunString:
+        def __reduce__(self):
+            return (ntu.runstring, (f"open({str(marker)!r}, 'w').write('x')", {}))
+
+    class NpLoad:
+        def __reduce__(self):
+            return (np.load, (str(tmp_path / "inner.npy"),), {"allow_pickle": True})
+
+    for evil in (RunString(), NpLoad()):
+        p = tmp_path / "evil.pkl"
+        p.write_bytes(pickle.dumps({"fitted_models": evil}))
+        with pytest.raises(pickle.UnpicklingError):
+            load_poly(str(p))
+    assert not marker.exists()
+    # a legitimate payload (dict of numpy arrays / scalars) still loads
+    good = {"fitted_models": {k: {"coef": np.arange(34.0) + i, "intercept": np.float64(i)} for i, k in
+                              enumerate(["CX", "CY", "CZ", "Cl", "Cm", "Cn"])}}
+    p = tmp_path / "good.pkl"
+    p.write_bytes(pickle.dumps(good))
+    coef, ic = load_poly(str(p))
+    assert coef.shape == (6, 34) and np.array_equal(ic, np.arange(6.0))
+
+
 def test_synthetic_inputs_are_in_envelope_and_seeded():
     from aircraft_amd.synthetic import synthetic_problem, synthetic_units
 
@@ -224,3 +258,27 @@ def test_trajectory_io_round_trip(tmp_path):
     assert tio.list_iterations(path) == [9] and tio.load_trajectory(path, 9).state.dtype == np.float64
     with pytest.raises(FileNotFoundError):
         tio.load_trajectory(str(tmp_path / "nope.h5"), 0)
+
+
+def test_bench_self_launch_plan_and_cpu_refusal():
+    """bench.py --gpus N without a launcher: N rank environments (one process per GPU, rendezvous on 127.0.0.1), built
+    before anything touches the GPU; on a box without GPUs the ranks fail loudly and the parent exits non-zero."""
+    import subprocess
+    import sys
+
+    import bench
+
+    envs = bench.rank_environments(4, base_env={"PATH": "/usr/bin"}, port=29999)
+    assert [e["RANK"] for e in envs] == ["0", "1", "2", "3"] and all(e["WORLD_SIZE"] == "4" for e in envs)
+    assert all(e["LOCAL_RANK"] == e["RANK"] and e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "29999"
+               and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in envs)
+    assert bench.parse(["--gpus", "8"]).scaling == "both"
+    import torch
+
+    if torch.cuda.is_available():
+        return  # the GPU suite covers the live launch (tests/test_gpu_multigpu.py)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert "starting 2 rank processes" in r.stderr
