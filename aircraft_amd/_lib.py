@@ -90,6 +90,7 @@ PROTOTYPES = {
     "ac_last_error": (C.c_char_p, []),
     "ac_version": (C.c_char_p, []),
     "ac_device_arch": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "ac_hess_workspace": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_size_t)]),
     "ac_last_launch": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                  C.POINTER(C.c_int)]),
 }

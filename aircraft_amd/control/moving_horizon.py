@@ -35,7 +35,7 @@ class RecedingHorizon:
         """overlap: nodes of each solve that are discarded (mhtt.py:77); iterations: iLQR iterations per solve;
         warm_start: 'shift' re-uses the tail of the previous controls, 'zero' restarts from zero controls as the
         reference's MHTT.initialise does (control/moving_horizon.py:204)."""
-        assert 0 <= overlap < solver.num_nodes
+        assert 0 <= overlap < solver.num_nodes and iterations >= 0
         self.solver, self.overlap, self.iterations, self.warm_start = solver, overlap, iterations, warm_start
         self.keep = solver.num_nodes - overlap
         self._graph = None
@@ -57,8 +57,11 @@ class RecedingHorizon:
         """One solve + shift on the allocated buffers (capturable: no allocation, no host sync)."""
         torch = _torch()
         s = self.solver
+        J = None
         for _ in range(self.iterations):
             J, _ = s.iterate(self.x0, self.X, self.U)
+        if J is None:  # iterations == 0: the loop alone (keep / shift / re-rollout), no solve
+            J = s.trajectory_cost(self.X, self.U)
         self.cost.copy_(J)
         self.executed.copy_(self.X[1 : self.keep + 1])
         # advance: the state reached after the kept nodes becomes the next initial state

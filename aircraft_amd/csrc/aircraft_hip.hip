@@ -967,6 +967,13 @@ int ac_rollout_policy_f32(ac_handle* h, const ac_ilqr_cost* limits, const float*
     return AC_OK;
 }
 
+int ac_hess_workspace(const ac_handle* h, float** ptr, size_t* floats) {
+    if (!h) return AC_ERR_BAD_ARG;
+    if (ptr) *ptr = h->d_hess_ws;
+    if (floats) *floats = h->hess_ws_floats;
+    return AC_OK;
+}
+
 int ac_last_launch(const ac_handle* h, char* name, size_t len, int* grid, int* block, int* lds_bytes) {
     if (!h) return AC_ERR_BAD_ARG;
     if (name && len) snprintf(name, len, "%s", h->last_name);

@@ -244,6 +244,9 @@ int ac_mhtt_loss_f32(ac_handle* h, const ac_mhtt_weights* weights, const float* 
 const char* ac_last_error(void);     /* thread-local text of the last failing HIP call */
 const char* ac_version(void);
 int ac_device_arch(char* buf, size_t len);  /* gcnArchName of the current device */
+/* Device pointer and size (floats) of the handle's second-order workspace (tests poison it with NaNs to prove that every
+ * element a second-order call reads was written by that call). */
+int ac_hess_workspace(const ac_handle* h, float** ptr, size_t* floats);
 /* Name + launch geometry of the kernel the last call on this handle dispatched (for profiling). */
 int ac_last_launch(const ac_handle* h, char* name, size_t len, int* grid, int* block, int* lds_bytes);
 

@@ -85,7 +85,7 @@ def test_single_layer_and_odd_width_networks(gpu):
             MlpData([rng.normal(0, 0.4, (100, 5)), rng.normal(0, 0.1, (6, 100))], [rng.normal(0, 0.1, 100), rng.normal(0, 0.1, 6)],
                     [1, 0], *sc)]
     import torch
-    from tests.helpers import rel_fro
+    from tests.helpers import rel_fro, unit_max_rel
     from aircraft_amd import Aircraft, AircraftConfiguration, AircraftOpts
     from aircraft_amd.synthetic import GLIDER
 
@@ -100,6 +100,7 @@ def test_single_layer_and_odd_width_networks(gpu):
         Xr, Ar, Br, cr = orc.step_sens(X, U, 0.01)
         assert block_rel_err(Xn.cpu().numpy(), Xr) < 1e-5
         assert rel_fro(A.cpu().numpy(), Ar) < 1e-4 and rel_fro(Bm.cpu().numpy(), Br) < 1e-4
+        assert unit_max_rel(A.cpu().numpy(), Ar).max() < 1e-4 and unit_max_rel(Bm.cpu().numpy(), Br).max() < 1e-4  # per unit
         assert block_rel_err(ac.state_update(Xd, Ud, 0.01).cpu().numpy(), Xr) < 1e-5
         Ur = np.repeat(U[None], 6, axis=0)
         roll = ac.rollout(Xd, torch.from_numpy(Ur).float().to(gpu), 0.01).cpu().numpy()

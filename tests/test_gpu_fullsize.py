@@ -3,7 +3,8 @@ size-independent properties, plus an oracle spot check on a random sample of the
 import numpy as np
 import pytest
 
-from tests.helpers import block_rel_err, f32_exact, make_aircraft, make_oracle, rel_fro
+from tests.helpers import (block_rel_err, check_against_conditioning, conditioning, f32_exact, make_aircraft, make_oracle,
+                           parity_report, unit_max_rel, unit_rowblock_rel)
 from aircraft_amd.synthetic import synthetic_controls, synthetic_states, synthetic_units
 
 pytestmark = pytest.mark.gpu
@@ -41,7 +42,10 @@ def test_cfg3_oracle_spot_check(cfg3):
     Bm = cfg3["Bm"].cpu().numpy()[k, :, :, b].transpose(1, 2, 0)
     c = cfg3["c"].cpu().numpy()[k, :, b].T
     assert block_rel_err(F, Xr) < 1e-5
-    assert rel_fro(A, Ar) < 1e-4 and rel_fro(Bm, Br) < 1e-4 and rel_fro(c, cr) < 1e-4
+    for key, g, w in (("A", A, Ar), ("B", Bm, Br), ("c", c, cr)):  # every sampled unit on its own
+        e, eb = unit_max_rel(g, w), unit_rowblock_rel(g, w)
+        parity_report("cfg3_spot_check", block=key, units=512, unit_rel_max=float(e.max()), rowblock_rel_max=float(eb.max()))
+        assert e.max() < 1e-5 and eb.max() < 1e-4, (key, float(e.max()), float(eb.max()))
 
 
 def test_cfg3_deterministic_and_shard_invariant(cfg3):
@@ -106,6 +110,18 @@ def test_cfg3_rollout_chains_the_step(cfg3):
     assert float((traj[-1, 6:10].norm(dim=0) - 1).abs()[fin[-1]].max()) < 1e-6
 
 
+def test_cfg3_full_rollout_against_the_oracle(cfg3):
+    """The whole cfg3 rollout — 4096 instances x 50 nodes, cooperative register-resident kernel — against the float64
+    oracle on EVERY instance (2e5 float64 steps: seconds on the host), no mask: an instance is within 1e-5 at every node
+    or within 8 x the deviation the float64 reference itself shows under a one-ulp perturbation of x0."""
+    ms, X, U = cfg3["ms"], cfg3["X"], cfg3["U"]
+    traj = ms.rollout(X[0].contiguous(), U).cpu().numpy()
+    orc = make_oracle(cfg3["ac"])
+    X0, Uh = cfg3["Xh"][0], cfg3["Uh"]
+    ref, cond = conditioning(orc, np.ascontiguousarray(X0), np.ascontiguousarray(Uh), 0.01, draws=2)
+    check_against_conditioning("cfg3_full_rollout[4096x50]", traj, ref, cond, 1e-5, min_frac=0.9)
+
+
 def test_cfg4_shard_shape(gpu):
     """cfg4: one rank's shard of B=16384 (2048 instances), H=100: shapes, finiteness, oracle sample."""
     from aircraft_amd.control import MultipleShooting
@@ -122,7 +138,57 @@ def test_cfg4_shard_shape(gpu):
     k = rng.integers(0, 100, 128); b = rng.integers(0, 2048, 128)
     Xr, Ar, Br, _ = make_oracle(ac).step_sens(np.ascontiguousarray(Xh[k, :, b].T), np.ascontiguousarray(Uh[k, :, b].T), 0.01)
     assert block_rel_err(F.cpu().numpy()[k, :, b].T, Xr) < 1e-5
-    assert rel_fro(A.cpu().numpy()[k, :, :, b].transpose(1, 2, 0), Ar) < 1e-4
+    assert unit_max_rel(A.cpu().numpy()[k, :, :, b].transpose(1, 2, 0), Ar).max() < 1e-5
+    assert unit_max_rel(Bm.cpu().numpy()[k, :, :, b].transpose(1, 2, 0), Br).max() < 1e-5
+
+
+def test_cfg4_shard_solve_cost_topk_and_gather(gpu):
+    """cfg4 on one rank: its shard of the 16 384 random restarts (2048 instances), H = 100, 4x128 surrogate — a batched
+    solve of 2 iterations, the K6 trajectory-cost kernel, top-K selection and the record exchange (identity at world
+    size 1).  The winning records are dynamically consistent: the float64 oracle's rollout of the winning controls
+    reproduces the winning states."""
+    import torch
+
+    from aircraft_amd.control import ILQR, QuadraticCost
+    from aircraft_amd.distributed import gather_best, shard_bounds, trajectory_cost
+    from aircraft_amd.synthetic import TRIM_STATE
+
+    lo, hi = shard_bounds(16384, 3, 8)
+    B, H, k = hi - lo, 100, 4
+    ac = make_aircraft("nn", hidden=(128, 128, 128, 128))
+    cost = QuadraticCost.goal((50.0, 2.0), w_goal=1.0, height=-200.0, w_height=1.0, w_lateral_speed=0.5, r=0.5, reg=1.0)
+    solver = ILQR(system=ac, dt=0.01, num_nodes=H, cost=cost, alphas=(1.0, 0.5, 0.1))
+    rng = np.random.default_rng(1234)
+    U_all = np.zeros((H, 7, 16384), dtype=np.float32)
+    U_all[:, :3] = np.clip(np.cumsum(rng.normal(0, 0.3, (H, 3, 16384)), axis=0), -5, 5)
+    x0 = torch.from_numpy(np.repeat(TRIM_STATE[:, None], B, axis=1).astype(np.float32)).to(gpu)
+    U0 = torch.from_numpy(np.ascontiguousarray(U_all[:, :, lo:hi])).to(gpu)
+    X, U, hist = solver.solve(x0, U0, iters=2)
+    h = hist.cpu().numpy()
+    assert X.shape == (H + 1, 13, B) and U.shape == (H, 7, B) and h.shape == (3, B)
+    fin = np.isfinite(h).all(axis=0)
+    assert fin.mean() > 0.95
+    assert (np.diff(h[:, fin], axis=0) <= 1e-6 * np.abs(h[:-1, fin]) + 1e-6).all()  # monotone per instance
+    assert np.median(h[-1, fin] / h[0, fin]) < 0.9
+    # the one exchange: best-k by the solver's own cost, and by the K6 goal-distance kernel
+    c, Xb, Ub = gather_best(X, U, None, k=k, cost=hist[-1])
+    assert c.shape == (k,) and Xb.shape == (k, H + 1, 13) and Ub.shape == (k, H, 7)
+    order = torch.argsort(torch.nan_to_num(hist[-1], nan=float("inf")))[:k]
+    assert torch.equal(c, hist[-1][order]) and torch.equal(Xb[0], X[:, :, order[0]]) and torch.equal(Ub[0], U[:, :, order[0]])
+    goal = torch.tensor([50.0, 2.0, -200.0], device=gpu)
+    ck = trajectory_cost(ac, X, goal)
+    d = X[:, 0:3, :].double() - goal.double()[None, :, None]
+    want = (d * d).sum(1).sum(0) + 10.0 * (d[-1] * d[-1]).sum(0)
+    okc = torch.isfinite(want)
+    assert float(((ck.double() - want).abs() / want.abs().clamp_min(1e-9))[okc].max()) < 5e-6
+    c2, Xb2, Ub2 = gather_best(X, U, goal, k=k, system=ac)
+    assert torch.equal(c2, ck[torch.argsort(torch.nan_to_num(ck, nan=float("inf")))[:k]])
+    # dynamic consistency of the winners against the float64 oracle
+    Uw = np.ascontiguousarray(Ub.cpu().numpy().astype(np.float64).transpose(1, 2, 0))  # (H, 7, k)
+    ref = make_oracle(ac).rollout(np.repeat(TRIM_STATE[:, None], k, axis=1), Uw, 0.01)
+    got = Xb.cpu().numpy().astype(np.float64).transpose(1, 2, 0)
+    parity_report("cfg4_winners_vs_oracle", err=block_rel_err(got, ref))
+    assert block_rel_err(got, ref) < 1e-5
 
 
 def test_hipgraph_capture_of_the_inner_step(gpu):

@@ -4,7 +4,7 @@ up (e.g. stall scaling x sub-stepped sensitivities x per-unit dt on a ragged bat
 import numpy as np
 import pytest
 
-from tests.helpers import (block_rel_err, f32_exact, make_aircraft, make_oracle, oracle_step_hessian, rel_fro,
+from tests.helpers import (block_rel_err, f32_exact, make_aircraft, make_oracle, oracle_step_hessian, rel_fro, unit_max_rel,
                            synthetic_units)
 
 pytestmark = pytest.mark.gpu
@@ -45,6 +45,8 @@ def test_random_configuration(gpu, seed):
     Xr, Ar, Br, cr = orc.step_sens(X, U, dts)
     assert block_rel_err(Xn.cpu().numpy(), Xr) < 5e-6, tag
     assert rel_fro(A.cpu().numpy(), Ar) < 2e-5 and rel_fro(Bm.cpu().numpy(), Br) < 1e-4 and rel_fro(c.cpu().numpy(), cr) < 1e-4, tag
+    for g_, w_ in ((A, Ar), (Bm, Br), (c, cr)):  # and every unit on its own (max norm)
+        assert unit_max_rel(g_.cpu().numpy(), w_).max() < 1e-4, tag
     # second-order blocks (one RK4 sub-step only)
     if substeps == 1 and n <= 250:
         lam = f32_exact(rng.normal(size=(13, n)))

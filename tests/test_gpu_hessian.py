@@ -140,3 +140,90 @@ def test_wide_valu_flavour_is_refused(gpu):
     x = torch.zeros((13, 4), device=gpu); x[3] = 30.0; x[9] = 1.0
     with pytest.raises(AircraftHipError, match="UNSUPPORTED"):
         ac.step_hess(x, torch.zeros((7, 4), device=gpu), 0.01, torch.ones((13, 4), device=gpu))
+
+
+def _single_layer_aircraft(act_last, normalise=True, seed=11):
+    """A net that IS one Linear(5, 6) layer (optionally tanh on it): the L == 1 path of the engines (layer<1,1>, no
+    first/hidden/last split, 21-slab second-order pass at WT = 2)."""
+    from aircraft_amd import Aircraft, AircraftConfiguration, AircraftOpts, MlpData
+    from tests.helpers import GLIDER
+
+    base = MlpData.synthetic((16,), seed=seed)
+    rng = np.random.default_rng(seed)
+    W = (rng.uniform(-1, 1, (6, 5)) / np.sqrt(5)).astype(np.float32)
+    b = rng.uniform(-0.3, 0.3, 6).astype(np.float32)
+    md = MlpData([W], [b], [act_last], base.input_mean, base.input_std, base.output_mean, base.output_std)
+    ac = Aircraft(AircraftOpts(coeff_model_type="nn", coeff_model_path=md, aircraft_config=AircraftConfiguration(dict(GLIDER)),
+                               physical_integration_substeps=1))
+    ac.normalise = normalise
+    return ac
+
+
+@pytest.mark.parametrize("act_last", [0, 1])
+def test_single_layer_net_first_and_second_order(gpu, act_last):
+    """L == 1 nets directly (identity and tanh last layer) through step, step_sens and step_hess: the path the folded
+    all-linear net of test_activation_free_layers_are_folded reaches only through the host-side fold."""
+    from tests.helpers import block_rel_err, parity_report, unit_max_rel
+
+    ac = _single_layer_aircraft(act_last)
+    orc = make_oracle(ac)
+    X, U, lam = units(150, seed=51)  # ragged
+    Xn, A, Bm, c = ac.step_sens(dev(X, gpu), dev(U, gpu), 0.01)
+    Xr, Ar, Br, cr = orc.step_sens(X, U, 0.01)
+    assert block_rel_err(Xn.cpu().numpy(), Xr) < 1e-5
+    for key, g_, w_ in (("A", A, Ar), ("B", Bm, Br), ("c", c, cr)):
+        e = unit_max_rel(g_.cpu().numpy(), w_)
+        assert e.max() < 1e-4, (key, float(e.max()))
+    Hm = ac.step_hess(dev(X, gpu), dev(U, gpu), 0.01, dev(lam, gpu)).cpu().numpy().astype(np.float64)
+    want = oracle_step_hessian(orc, X, U, 0.01, lam)
+    assert np.isfinite(Hm).all()
+    parity_report(f"single_layer_hess[act={act_last}]", rel_block=rel_block(Hm, want))
+    assert rel_block(Hm, want) < 5e-4
+    # same handle, repeated: identical bits (no dependence on what earlier calls left in registers / LDS / workspace)
+    H2 = ac.step_hess(dev(X, gpu), dev(U, gpu), 0.01, dev(lam, gpu)).cpu().numpy().astype(np.float64)
+    assert np.array_equal(Hm, H2)
+
+
+@pytest.mark.parametrize("hidden", [None, (64, 64, 64), (128, 128, 128, 128), "single", "folded"])
+def test_hessian_reads_nothing_it_did_not_write(gpu, hidden):
+    """Poison the handle's stage-tensor workspace and the output with NaNs before the call: if any element the
+    second-order kernels read was not written by THIS call (an unwritten workspace row, a stale output entry), the NaN
+    reaches the result.  Covers the L == 1 / 21-slab path (the reference's own net is Linear-tanh-Linear: 5-32-6 after
+    the fold is L == 2; 'single' and 'folded' are L == 1), width 64 (one 21-slab pass) and width 128 (29 slab evaluations)."""
+    import ctypes as C
+
+    import torch
+
+    from aircraft_amd import Aircraft, AircraftConfiguration, AircraftOpts, MlpData, _lib
+    from tests.helpers import GLIDER
+
+    if hidden == "single":
+        ac = _single_layer_aircraft(1)
+    elif hidden == "folded":
+        base = MlpData.synthetic((48, 24, 40), seed=5)
+        md = MlpData(base.weights, base.biases, [0, 0, 0, 0], base.input_mean, base.input_std, base.output_mean, base.output_std)
+        ac = Aircraft(AircraftOpts(coeff_model_type="nn", coeff_model_path=md, aircraft_config=AircraftConfiguration(dict(GLIDER)),
+                                   physical_integration_substeps=1))
+        ac.normalise = True
+    else:
+        ac = make_aircraft("nn", hidden=hidden, normalise=True)
+    n = 200
+    X, U, lam = units(n, seed=61)
+    Xd, Ud, Ld = dev(X, gpu), dev(U, gpu), dev(lam, gpu)
+    clean = ac.step_hess(Xd, Ud, 0.01, Ld).clone()
+    assert torch.isfinite(clean).all()
+    lib = _lib.load()
+    ptr, floats = C.c_void_p(), C.c_size_t()
+    assert lib.ac_hess_workspace(ac._handle, C.byref(ptr), C.byref(floats)) == 0
+    assert floats.value >= n * 504 and ptr.value
+    # NaN the whole workspace through a raw device memset pattern (0xFF bytes = NaN) and the output buffer
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    torch.cuda.synchronize()
+    assert hip.hipMemset(ptr, 0xFF, floats.value * 4) == 0
+    assert hip.hipDeviceSynchronize() == 0
+    out = torch.full((21, 21, n), float("nan"), device=gpu)
+    got = ac.step_hess(Xd, Ud, 0.01, Ld, out=out)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, clean)

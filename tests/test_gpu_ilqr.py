@@ -190,3 +190,32 @@ def test_exact_hessian_loop_is_graph_capturable(gpu, model, hidden):
     hg = RecedingHorizon(newton, overlap=12, iterations=2).allocate(dev(X0, gpu), U0).capture().run(4, record=True)
     assert he.shape == (4 * 8 + 1, 13, 64)
     assert block_rel_err(hg.cpu().numpy(), he.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("warm_start", ["shift", "zero"])
+@pytest.mark.parametrize("iterations", [0, 2])
+def test_receding_horizon_loop_matches_numpy_restatement(gpu, warm_start, iterations):
+    """a19: the closed loop against oracle/receding_oracle.py (a float64 restatement of main/mhe/mhtt.py:79-124 around
+    the NumPy iLQR sweep and the C++ oracle's dynamics): which nodes are kept, which state restarts the next solve, how the
+    controls are shifted / zeroed, what the re-rollout produces.  iterations = 0 isolates the loop itself."""
+    import receding_oracle as ro
+    from aircraft_amd.control import RecedingHorizon
+
+    B, H, overlap, cycles = 6, 20, 12, 3
+    ac, il, cost, X0, U = setup(gpu, "poly", None, B=B, H=H)
+    U0 = U if iterations == 0 else np.zeros_like(U)  # a non-trivial control sequence when nothing re-solves it
+    loop = RecedingHorizon(il, overlap=overlap, iterations=iterations, warm_start=warm_start).allocate(dev(X0, gpu), dev(U0, gpu))
+    hist = loop.run(cycles, record=True).cpu().numpy().astype(np.float64)
+    want, x0_w, U_w, choices = ro.receding_horizon(make_oracle(ac), cost, X0, U0, overlap, iterations, cycles, il.alphas, 0.01,
+                                                   warm_start=warm_start)
+    keep = H - overlap
+    assert hist.shape == want.shape == (cycles * keep + 1, 13, B)
+    assert np.array_equal(hist[0], X0.astype(np.float32))
+    assert block_rel_err(hist, want) < (1e-5 if iterations == 0 else 5e-5), block_rel_err(hist, want)
+    assert block_rel_err(loop.x0.cpu().numpy()[None], x0_w[None]) < (1e-5 if iterations == 0 else 5e-5)
+    # controls carried into the next cycle (degrees): shifted tail / zeros
+    assert np.abs(loop.U.cpu().numpy() - U_w).max() < (1e-6 if iterations == 0 else 2e-3)
+    if warm_start == "zero":
+        assert not loop.U.cpu().numpy().any()
+    if iterations:
+        assert all((c >= 0).any() for ch in choices for c in ch)  # the solver did move the iterate in every cycle

@@ -3,20 +3,43 @@
 Tolerances (stated per north_star: <= 1e-5 relative on state):
   STATE_TOL  block-relative error of x+ / trajectories:  max_block |dx|_inf / max(|x_ref|_inf, floor)  <= 1e-5
   DERIV_TOL  same metric on x_dot                                                                <= 2e-5
-  SENS_TOL   Frobenius-relative error of A, B, c per call                                         <= 1e-4
+  SENS_TOL   PER-UNIT max-norm relative error of A, B, c: max|dA| / max|A_ref| of every single unit   <= 1e-5
+             (and SENS_BLOCK_TOL on the worst p / v / q / omega ROW block of every unit, helpers.unit_rowblock_rel)
 fp32 arithmetic against an fp64 reference: one RK4 step carries ~1e-7, a 50-step rollout ~1e-6.
+Chained evaluations (rollouts, sub-steps) are checked on EVERY instance against max(STATE_TOL, 8 x the deviation of the
+float64 reference itself under a one-ulp input perturbation) — helpers.check_against_conditioning — and the fraction of
+instances inside the plain 1e-5 bar is reported (gpurun_out/parity_report.jsonl) and bounded from below.
 """
 import numpy as np
 import pytest
 
-from tests.helpers import (block_rel_err, f32_exact, golden, in_envelope, make_aircraft, make_oracle,
-                           near_trim_problem, rel_fro, synthetic_problem, synthetic_units, well_conditioned)
+from tests.helpers import (block_rel_err, check_against_conditioning, conditioning, f32_exact, golden, in_envelope,
+                           make_aircraft, make_oracle, near_trim_problem, parity_report, synthetic_problem,
+                           synthetic_units, unit_max_rel, unit_rowblock_rel)
 
 pytestmark = pytest.mark.gpu
 
 STATE_TOL = 1e-5
 DERIV_TOL = 2e-5
-SENS_TOL = 1e-4
+SENS_TOL = 1e-5        # measured worst unit, all models: 4.3e-6 (poly, c)
+SENS_BLOCK_TOL = 1e-4  # measured worst row block of any unit: 2.1e-5 (poly, c)
+
+
+def assert_sens(name, got, want, tol=SENS_TOL, block_tol=SENS_BLOCK_TOL):
+    """Every unit on its own: max-norm relative error of the whole block and of its worst row block."""
+    for key, g, w in got_want_pairs(got, want):
+        e, eb = unit_max_rel(g, w), unit_rowblock_rel(g, w)
+        parity_report(name, block=key, units=int(e.size), unit_rel_max=float(e.max()), unit_rel_p50=float(np.median(e)),
+                      rowblock_rel_max=float(eb.max()), rowblock_rel_p50=float(np.median(eb)))
+        assert e.max() < tol, (name, key, "worst unit", int(e.argmax()), float(e.max()))
+        assert eb.max() < block_tol, (name, key, "worst unit (row block)", int(eb.argmax()), float(eb.max()))
+
+
+def got_want_pairs(got, want):
+    for key in ("A", "B", "c"):
+        if got.get(key) is not None:
+            g = got[key]
+            yield key, (g.cpu().numpy() if hasattr(g, "cpu") else g), want[key]
 
 ANALYTIC = ["default", "linear", "poly"]
 NN_CONFIGS = {  # name -> (hidden, use_mfma)
@@ -73,8 +96,6 @@ def test_state_derivative(gpu, model):
 @pytest.mark.parametrize("model", ALL_MODELS)
 @pytest.mark.parametrize("substeps,normalise", [(1, True), (1, False), (10, False)])
 def test_state_update(gpu, model, substeps, normalise):
-    if model == "cfg2_3x64_valu" and substeps == 10:
-        pytest.skip("VALU validation path: covered at substeps=1")
     ac = build(model, substeps=substeps, normalise=normalise)
     n = 777
     X, U = synthetic_units(n, seed=5)
@@ -84,10 +105,10 @@ def test_state_update(gpu, model, substeps, normalise):
         ref = make_oracle(ac).state_update(X, U, dt)
         assert block_rel_err(out, ref) < STATE_TOL  # every unit, no mask
     else:
-        # 10 chained sub-steps (0.1 s) from a random state can tumble or leave RK4's stability region
-        ok, ref = well_conditioned(make_oracle(ac), X, U, dt, tol=5e-7, rollout=False)
-        assert ok.mean() > 0.2, ok.mean()
-        assert block_rel_err(out[:, ok], ref[:, ok]) < STATE_TOL
+        # 10 chained sub-steps (0.1 s) from a random state can tumble or leave RK4's stability region: every unit is
+        # checked against max(1e-5, 8 x the reference's own one-ulp deviation); at least 90 % must meet 1e-5 outright
+        ref, cond = conditioning(make_oracle(ac), X, U, dt, rollout=False)
+        check_against_conditioning(f"state_update[{model}-10]", out, ref, cond, STATE_TOL, min_frac=0.9)
     if normalise:
         assert np.abs(np.linalg.norm(out[6:10], axis=0) - 1).max() < 1e-6
 
@@ -112,9 +133,7 @@ def test_step_sens(gpu, model):
     Xn, A, Bm, c = ac.step_sens(dev(X, gpu), dev(U, gpu), 0.01)
     Xr, Ar, Br, cr = make_oracle(ac).step_sens(X, U, 0.01)
     assert block_rel_err(Xn.cpu().numpy(), Xr) < STATE_TOL
-    assert rel_fro(A.cpu().numpy(), Ar) < SENS_TOL
-    assert rel_fro(Bm.cpu().numpy(), Br) < SENS_TOL
-    assert rel_fro(c.cpu().numpy(), cr) < SENS_TOL
+    assert_sens(f"step_sens[{model}]", {"A": A, "B": Bm, "c": c}, {"A": Ar, "B": Br, "c": cr})
     # structure the reference's force model implies exactly: dF/dp = [I;0], dF/dthrust = 0
     A_ = A.cpu().numpy()
     assert np.array_equal(A_[:, :3, :], np.broadcast_to(np.eye(13)[:, :3, None], (13, 3, n)))
@@ -130,7 +149,7 @@ def test_step_sens_unnormalised_and_stall(gpu, model):
     assert c is None
     Xr, Ar, Br, _ = make_oracle(ac).step_sens(X, U, dt)
     assert block_rel_err(Xn.cpu().numpy(), Xr) < STATE_TOL
-    assert rel_fro(A.cpu().numpy(), Ar) < SENS_TOL and rel_fro(Bm.cpu().numpy(), Br) < SENS_TOL
+    assert_sens(f"step_sens_unnormalised_stall[{model}]", {"A": A, "B": Bm}, {"A": Ar, "B": Br})
 
 
 def test_cfg1_single_glider_rollout(gpu):
@@ -163,18 +182,25 @@ ROLLOUT_CASES = [("default", 257, 50), ("linear", 100, 8), ("poly", 257, 50), ("
                  ("cfg2_3x64", 256, 50), ("cfg2_3x64_valu", 70, 20), ("cfg3_4x128", 64, 50), ("cfg3_4x128", 320, 100)]
 
 
+# lower bounds on the fraction of instances (with a finite float64 reference) that meet the plain 1e-5 bar at EVERY node
+# (measured, round 2: 0.978 .. 1.0 — gpurun_out/parity_report.jsonl, profiles/r02_parity_report.jsonl)
+ROLLOUT_MIN_FRAC = {"default": 0.95, "linear": 0.95, "poly": 0.95, "real": 0.95, "cfg2_3x64": 0.98, "cfg2_3x64_valu": 0.98,
+                    "cfg3_4x128": 0.98}
+
+
 @pytest.mark.parametrize("model,B,H", ROLLOUT_CASES)
 def test_rollout(gpu, model, B, H):
-    """SURVEY-spec random states and +-5 deg control walks.  Many such open-loop trajectories leave the envelope and
-    tumble (omega of tens of rad/s), where rounding-level differences grow exponentially in ANY arithmetic; parity is
-    asserted on the instances whose float64 reference is itself reproducible under a one-ulp input perturbation."""
+    """SURVEY-spec random states and +-5 deg control walks, every instance checked.  Many such open-loop trajectories
+    leave the envelope and tumble (omega of tens of rad/s), where rounding-level differences grow exponentially in ANY
+    arithmetic: an instance must be within 1e-5 of the float64 reference at every node, or within 8 x the deviation that
+    reference itself shows under a one-ulp perturbation of x0; the fraction inside the plain 1e-5 bar is reported and
+    bounded from below."""
     ac = build(model, normalise=True)
     X0, U = synthetic_problem(B, H, seed=17)
     out = ac.rollout(dev(X0, gpu), dev(U, gpu), 0.01).cpu().numpy()
-    ok, ref = well_conditioned(make_oracle(ac), X0, U, 0.01)
-    assert ok.sum() >= 8, ok.sum()  # the assertion below must not be vacuous
+    ref, cond = conditioning(make_oracle(ac), X0, U, 0.01)
     assert np.array_equal(out[0], X0.astype(np.float32))
-    assert block_rel_err(out[:, :, ok], ref[:, :, ok]) < STATE_TOL
+    check_against_conditioning(f"rollout[{model}-{B}-{H}]", out, ref, cond, STATE_TOL, min_frac=ROLLOUT_MIN_FRAC[model])
 
 
 def test_simulation_h5_replay(gpu):
@@ -249,14 +275,15 @@ def test_activation_free_layers_are_folded(gpu, act):
     orc = make_oracle(ac)
     Xr, Ar, Br, cr = orc.step_sens(X, U, 0.01)
     assert block_rel_err(Xn.cpu().numpy(), Xr) < STATE_TOL
-    assert rel_fro(A.cpu().numpy(), Ar) < SENS_TOL and rel_fro(Bm.cpu().numpy(), Br) < SENS_TOL
-    assert rel_fro(c.cpu().numpy(), cr) < SENS_TOL
+    assert_sens(f"step_sens_folded{act}", {"A": A, "B": Bm, "c": c}, {"A": Ar, "B": Br, "c": cr})
     assert block_rel_err(ac.state_update(dev(X, gpu), dev(U, gpu), 0.01).cpu().numpy(), Xr) < STATE_TOL
     lam = np.random.default_rng(3).standard_normal((13, 150))
     lam = f32_exact(lam)
     Hd = ac.step_hess(dev(X, gpu), dev(U, gpu), 0.01, dev(lam, gpu)).cpu().numpy()
     Hr = oracle_step_hessian(orc, X, U, 0.01, lam)
-    assert rel_fro(Hd, Hr) < 2e-3
+    eh = unit_max_rel(Hd, Hr)  # every unit on its own
+    parity_report(f"step_hess_folded{act}", unit_rel_max=float(eh.max()), unit_rel_p50=float(np.median(eh)))
+    assert eh.max() < 2e-3, (int(eh.argmax()), float(eh.max()))
 
 
 def test_mfma_and_valu_paths_agree(gpu):

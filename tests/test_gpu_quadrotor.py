@@ -3,7 +3,7 @@ rigid-body kernels — against the float64 oracle."""
 import numpy as np
 import pytest
 
-from tests.helpers import block_rel_err, f32_exact, rel_fro
+from tests.helpers import block_rel_err, f32_exact, rel_fro, unit_max_rel
 
 pytestmark = pytest.mark.gpu
 
@@ -92,6 +92,7 @@ def test_quadrotor_sensitivities(gpu, substeps, normalise):
     assert rel_fro(A.cpu().numpy(), Ar) < 1e-5
     assert rel_fro(Bm.cpu().numpy(), Br[:, :4]) < 1e-5 and not Br[:, 4:].any()
     assert rel_fro(c.cpu().numpy(), cr) < 1e-5
+    assert unit_max_rel(A.cpu().numpy(), Ar).max() < 2e-5 and unit_max_rel(Bm.cpu().numpy(), Br[:, :4]).max() < 2e-5  # per unit
     # a caller-provided 7-column buffer gets zeros in the three unused columns
     import torch
     out = (torch.empty(13, 300, device=gpu), torch.empty(13, 13, 300, device=gpu), torch.full((13, 7, 300), 9.0, device=gpu),
