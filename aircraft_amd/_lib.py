@@ -67,6 +67,11 @@ PROTOTYPES = {
     "ac_step_sens_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, _VP, _VP, _VP, _VP, _VP]),
     "ac_shoot_step_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, C.c_long, _VP, _VP]),
     "ac_shoot_sens_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP, _VP]),
+    "ac_state_derivative_sens_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, _VP, _VP, _VP, _VP]),
+    "ac_shoot_derivative_sens_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP]),
+    "ac_envelope_f32": (C.c_int, [_VP, _VP, C.c_long, _VP, _VP, _VP]),
+    "ac_shoot_envelope_f32": (C.c_int, [_VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP]),
+    "ac_quat_rows_f32": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP]),
     "ac_step_hess_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _VP, C.c_long, _VP, _VP]),
     "ac_reserve_hess_workspace": (C.c_int, [_VP, C.c_long]),
     "ac_shoot_hess_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),

@@ -106,10 +106,101 @@ class MultipleShooting:
         del keep
         return out
 
-    def defects(self, X, U, dt=None):
-        """r_k = x_{k+1} - F(x_k, u_k, dt_k), (N, 13, B)  (control/base.py:279-280)."""
+    def defects(self, X, U, dt=None, integration: Optional[str] = None):
+        """Defect rows of every node, (N, 13, B) — ControlProblem.state_constraint (control/base.py:275-286):
+            'explicit'  r_k = x_{k+1} - F(x_k, u_k, dt_k)                      (:279-280)
+            'implicit'  r_k = x_{k+1} - (x_k + dt_k f(x_{k+1}, u_k))           (:282-284)
+        `integration` defaults to opts['integration'] (default 'explicit', as in the reference)."""
+        mode = integration or self.opts.get("integration", "explicit")
         H = U.shape[0]
-        return X[1 : H + 1] - self.propagate(X, U, dt)
+        if mode == "explicit":
+            return X[1 : H + 1] - self.propagate(X, U, dt)
+        if mode != "implicit":
+            raise NotImplementedError("Must choose integration mode from ['implicit', 'explicit']")  # base.py:286
+        f, _, _ = self.derivative_sens(X[1 : H + 1], U)
+        return X[1 : H + 1] - X[:H] - self._dt_tensor(dt, X) * f
+
+    def _dt_tensor(self, dt, X):
+        torch = _torch()
+        if dt is None:
+            dt = self.dt
+        if isinstance(dt, torch.Tensor) and dt.numel() > 1:
+            return dt.to(device=X.device, dtype=torch.float32)[:, None, :]
+        return float(dt)
+
+    def derivative_sens(self, Xn, Un, out=None):
+        """f, Fx = df/dx, Fu = df/du at the H (state, control) pairs Xn (H, 13, B) [a view such as X[1:] is used in
+        place], Un (H, 7, B): (H,13,B), (H,13,13,B), (H,13,7,B)."""
+        torch = _torch()
+        lib = self.system._sync()
+        H, B = Un.shape[0], Un.shape[2]
+        assert Xn.is_cuda and Xn.is_contiguous() and Un.is_contiguous() and Xn.shape == (H, self.state_dim, B)
+        assert Un.shape[1] == _lib.NUM_CONTROLS and Xn.dtype == torch.float32 and Un.dtype == torch.float32
+        ns, nc = self.state_dim, _lib.NUM_CONTROLS
+        if out is None:
+            out = (torch.empty((H, ns, B), device=Xn.device), torch.empty((H, ns, ns, B), device=Xn.device),
+                   torch.empty((H, ns, nc, B), device=Xn.device))
+        f, Fx, Fu = out
+        _lib.check(lib.ac_shoot_derivative_sens_f32(self.system._handle, Xn.data_ptr(), Un.data_ptr(), B, H, f.data_ptr(),
+                                                    Fx.data_ptr(), Fu.data_ptr(), self.system._stream()),
+                   "ac_shoot_derivative_sens_f32")
+        return f, Fx, Fu
+
+    def linearise_implicit(self, X, U, dt=None):
+        """Jacobian blocks of the implicit defect rows r_k = x_{k+1} - x_k - dt_k f(x_{k+1}, u_k):
+            d r_k / d x_k = -I,   d r_k / d x_{k+1} = I - dt_k Fx,   d r_k / d u_k = -dt_k Fu,   d r_k / d dt_k = -f
+        Returns (r, Jnext (N,13,13,B), Ju (N,13,7,B), jdt (N,13,B)); Fx, Fu, f come from ONE launch of the derivative-
+        sensitivity kernel on the next nodes, the scaling below is elementwise."""
+        torch = _torch()
+        H = U.shape[0]
+        f, Fx, Fu = self.derivative_sens(X[1 : H + 1], U)
+        dtt = self._dt_tensor(dt, X)
+        r = X[1 : H + 1] - X[:H] - dtt * f
+        d4 = dtt[:, None] if isinstance(dtt, torch.Tensor) else dtt
+        eye = torch.eye(self.state_dim, device=X.device)[None, :, :, None]
+        return r, eye - d4 * Fx, -(d4 * Fu), -f
+
+    def quaternion_rows(self, Xn, Un=None, mode: Optional[str] = None):
+        """Quaternion rows of ControlProblem.state_constraint on the nodes Xn (H, 13, B) (the NEXT nodes x_{k+1}):
+            'constraint'  q.q - 1                                          (control/base.py:285-286)
+            'baumgarte'   2 a phi_dot + b^2 phi, phi = q.q - 1, phi_dot = 2 q.q_dot(x_{k+1}, u_{k+1}), a = b = 2   (:288-304)
+        Returns (row (H,B), Jx (H,13,B), Ju (H,7,B)).  'baumgarte' needs the controls Un (H, 7, B) paired with Xn."""
+        torch = _torch()
+        lib = self.system._sync()
+        mode = mode or self.opts.get("quaternion", None)
+        if mode not in ("constraint", "baumgarte"):
+            raise ValueError("quaternion rows exist for opts['quaternion'] in ('constraint', 'baumgarte')")
+        H, B = Xn.shape[0], Xn.shape[2]
+        assert Xn.is_cuda and Xn.is_contiguous() and Xn.dtype == torch.float32
+        row = torch.empty((H, B), device=Xn.device)
+        Jx = torch.empty((H, 13, B), device=Xn.device)
+        Ju = torch.empty((H, 7, B), device=Xn.device)
+        keep = None
+        ptrs = [C.c_void_p(0)] * 3
+        if mode == "baumgarte":
+            if Un is None:
+                raise ValueError("'baumgarte' differentiates q_dot = f(x_{k+1}, u_{k+1}): pass the controls Un")
+            keep = self.derivative_sens(Xn, Un)
+            ptrs = [C.c_void_p(t.data_ptr()) for t in keep]
+        _lib.check(lib.ac_quat_rows_f32(self.system._handle, 1 if mode == "baumgarte" else 0, Xn.data_ptr(), *ptrs, B, H,
+                                        row.data_ptr(), Jx.data_ptr(), Ju.data_ptr(), self.system._stream()),
+                   "ac_quat_rows_f32")
+        del keep
+        return row, Jx, Ju
+
+    def envelope(self, X, want_jacobian: bool = True):
+        """Envelope rows of every node of X (H', 13, B) (control/aircraft.py:44-59): rows (H', 4, B) =
+        (|v_rel|^2, beta, alpha, z) and Jx (H', 4, 13, B)."""
+        torch = _torch()
+        lib = self.system._sync()
+        Hn, B = X.shape[0], X.shape[2]
+        assert X.is_cuda and X.is_contiguous() and X.dtype == torch.float32 and X.shape[1] == self.state_dim
+        rows = torch.empty((Hn, 4, B), device=X.device)
+        Jx = torch.empty((Hn, 4, 13, B), device=X.device) if want_jacobian else None
+        _lib.check(lib.ac_shoot_envelope_f32(self.system._handle, X.data_ptr(), B, Hn, rows.data_ptr(),
+                                             Jx.data_ptr() if Jx is not None else None, self.system._stream()),
+                   "ac_shoot_envelope_f32")
+        return rows, Jx
 
     def hessian(self, X, U, Lam, dt=None, out=None):
         """Second-order blocks of every node of every instance: out (N, 21, 21, B) = sum_i Lam[k, i, b] d2F_i/dz dz at

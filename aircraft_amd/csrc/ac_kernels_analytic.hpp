@@ -147,8 +147,9 @@ template <int N, bool QUAD = false> struct SensIOT {
     }
 
     // Store this lane's N tangent columns of the 13 outputs (+ its share of the constant columns).
+    // p_diag: the diagonal of the constant position block — 1 for the step (dF/dp = [I; 0]), 0 for f itself (df/dp = 0)
     static AC_DI void store(int g, const UnitAddr& ua, const Dual<N> x[13], float* __restrict__ A,
-                            float* __restrict__ Bm, float* __restrict__ c, bool constants) {
+                            float* __restrict__ Bm, float* __restrict__ c, bool constants, float p_diag = 1.f) {
         const long n = ua.blk;  // row stride
         float* Au = A + ua.off(169);
         float* Bu = Bm + ua.off(91);
@@ -165,7 +166,7 @@ template <int N, bool QUAD = false> struct SensIOT {
         if (constants && g < 3) {
 #pragma unroll
             for (int i = 0; i < 13; ++i) {
-                Au[((long)i * 13 + g) * n] = (i == g) ? 1.f : 0.f;  // dF/dp_g
+                Au[((long)i * 13 + g) * n] = (i == g) ? p_diag : 0.f;  // dF/dp_g
                 Bu[((long)i * 7 + (QUAD ? 4 : 3) + g) * n] = 0.f;  // dF/d(control without effect)
             }
         }
@@ -256,6 +257,146 @@ AC_DI void sens_update(const DevParams& P, Coeffs& coeffs, int g, int col, const
 // 1 KB/lane with four directions per lane and runs 1.9x faster with two (eight lanes per unit); the cheap default and
 // linear models prefer four (less redundant primal work).
 template <int MODEL> struct AnalyticSensN { static constexpr int value = (MODEL == AC_MODEL_POLY) ? 2 : 4; };
+// ---- x_dot = f(x, u) with its Jacobians (the implicit defect row and the Baumgarte row differentiate f, not the step:
+// control/base.py:282-304; the LQR wrapper: dynamics/base.py:51-52) -------------------------------------------------
+// One evaluation of f seeded like the first RK4 stage: k[i].d[j] = df_i / d(direction N g + j).
+template <int N, class Coeffs>
+AC_DI void deriv_seeded(const DevParams& P, Coeffs& coeffs, int g, const float xv[13], const float uv[7], Dual<N> k[13]) {
+    typedef SeedsT<N> Seeds;
+    Dual<N> xs[13], u[7];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) xs[i] = Seeds::state(g, i, xv[i]);
+    coeffs.prefetch(P, xs, uv);
+    Seeds::template controls<Coeffs::kModel == AC_MODEL_QUAD>(g, uv, u);
+    state_derivative(P, coeffs, xs, u, k);
+}
+
+template <int N, bool QUAD>
+AC_DI void deriv_store(int g, const UnitAddr& ua, const Dual<N> k[13], float* __restrict__ Xdot, float* __restrict__ Fx,
+                       float* __restrict__ Fu) {
+    const UnitAddr uo = ua.late();
+    if (g == 0) {
+        float* p = Xdot + uo.off(13);
+#pragma unroll
+        for (int i = 0; i < 13; ++i) p[(long)i * uo.blk] = k[i].v;
+    }
+    SensIOT<N, QUAD>::store(g, uo, k, Fx, Fu, nullptr, true, 0.f);  // df/dp = 0, df/d(dead controls) = 0; no dt column
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void k_deriv_sens(const DevParams P, const float* __restrict__ X,
+                                                       const float* __restrict__ U, long n, long blk,
+                                                       float* __restrict__ Xdot, float* __restrict__ Fx,
+                                                       float* __restrict__ Fu) {
+    constexpr int kAnN = AnalyticSensN<MODEL>::value;
+    constexpr int UPW = 4 * kAnN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane % UPW, g = lane / UPW;
+    const long unit_raw = ((long)blockIdx.x * (kBlock / 64) + wave) * UPW + col;
+    const bool live = unit_raw < n;
+    const long unit = live ? unit_raw : n - 1;
+    const UnitAddr ua(unit, blk);
+    float xv[13], uv[7];
+    load_rows<13>(X, ua, xv);
+    load_rows<7>(U, ua, uv);
+    Dual<kAnN> k[13];
+    AnalyticCoeffs<MODEL> coeffs;
+    deriv_seeded<kAnN>(P, coeffs, g, xv, uv, k);
+    if (live) deriv_store<kAnN, MODEL == AC_MODEL_QUAD>(g, ua, k, Xdot, Fx, Fu);
+}
+
+// ---- envelope rows of AircraftControl.state_constraint (control/aircraft.py:44-59) and their state Jacobian ---------
+//   rows[0] = v_rel . v_rel (20^2 .. 100^2)   rows[1] = beta (+-10 deg)   rows[2] = alpha (+-20 deg)   rows[3] = z (< 0)
+// One lane per unit; the rows depend on (v, q) only: Dual<7>.  rows [4][n]; Jx [4][13][n] (may be NULL).
+template <int INST = 0>  // a template only so that the header may be included by several translation units
+__global__ __launch_bounds__(kBlock) void k_envelope(const DevParams P, const float* __restrict__ X, long n, long blk,
+                                                     float* __restrict__ rows, float* __restrict__ Jx) {
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const UnitAddr ua(i, blk);
+    float xv[13];
+    load_rows<13>(X, ua, xv);
+    typedef Dual<7> T;
+    T x[13];
+#pragma unroll
+    for (int r = 0; r < 13; ++r) {
+        x[r] = T(xv[r]);
+        if (r >= 3 && r < 10) x[r].d[r - 3] = 1.f;
+    }
+    AeroPre<T> a;
+    aero_pre(P, x, a);
+    const T row[3] = {a.vr[0] * a.vr[0] + a.vr[1] * a.vr[1] + a.vr[2] * a.vr[2], a.beta, a.alpha};
+    float* ro = rows + ua.off(4);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) ro[(long)r * blk] = row[r].v;
+    ro[3L * blk] = xv[2];
+    if (Jx) {
+        float* jo = Jx + ua.off(52);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 13; ++j) {
+                float v = 0.f;
+                if (r < 3 && j >= 3 && j < 10) v = row[r].d[j - 3];
+                if (r == 3 && j == 2) v = 1.f;
+                jo[(long)(r * 13 + j) * blk] = v;
+            }
+    }
+}
+
+// ---- quaternion rows of ControlProblem.state_constraint (control/base.py:285-304) on the NEXT node ------------------
+//   mode 0 ('constraint'):  row = q . q - 1
+//   mode 1 ('baumgarte'):   row = 2 a phi_dot + b^2 phi,  phi = q . q - 1,  phi_dot = 2 q . q_dot,  a = b = 2   (:296-301)
+// with Jx = d row / dx [13][n] and Ju = d row / du [7][n] from x_dot, Fx = df/dx, Fu = df/du of the same (x, u).
+template <int INST = 0>
+__global__ __launch_bounds__(kBlock) void k_quat_rows(const float* __restrict__ X, const float* __restrict__ Xdot,
+                                                      const float* __restrict__ Fx, const float* __restrict__ Fu, long n,
+                                                      long blk, int mode, float* __restrict__ row,
+                                                      float* __restrict__ Jx, float* __restrict__ Ju) {
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const UnitAddr ua(i, blk);
+    float q[4], qd[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* xp = X + ua.off(13);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q[c] = xp[(long)(6 + c) * blk];
+    const float phi = (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]) - 1.0f;
+    float* jx = Jx + ua.off(13);
+    float* ju = Ju + ua.off(7);
+    if (mode == 0) {
+        row[ua.off(1)] = phi;
+#pragma unroll
+        for (int j = 0; j < 13; ++j) jx[(long)j * blk] = (j >= 6 && j < 10) ? 2.0f * q[j - 6] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) ju[(long)j * blk] = 0.f;
+        return;
+    }
+    const float* dp = Xdot + ua.off(13);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qd[c] = dp[(long)(6 + c) * blk];
+    const float alpha = 2.0f, beta = 2.0f;
+    const float phid = 2.0f * (q[0] * qd[0] + q[1] * qd[1] + q[2] * qd[2] + q[3] * qd[3]);
+    row[ua.off(1)] = 2.0f * alpha * phid + beta * beta * phi;
+    const float* fx = Fx + ua.off(169);
+    const float* fu = Fu + ua.off(91);
+#pragma unroll
+    for (int j = 0; j < 13; ++j) {
+        float s = 0.f;  // q . d(q_dot)/dx_j
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s = fmaf(q[c], fx[(long)((6 + c) * 13 + j) * blk], s);
+        float dphid = 2.0f * s, dphi = 0.f;
+        if (j >= 6 && j < 10) { dphid += 2.0f * qd[j - 6]; dphi = 2.0f * q[j - 6]; }
+        jx[(long)j * blk] = 2.0f * alpha * dphid + beta * beta * dphi;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s = fmaf(q[c], fu[(long)((6 + c) * 7 + j) * blk], s);
+        ju[(long)j * blk] = 2.0f * alpha * 2.0f * s;
+    }
+}
+
 template <int MODEL>
 __global__ __launch_bounds__(kBlock) void k_step_sens(const DevParams P, const float* __restrict__ X,
                                                       const float* __restrict__ U, float dt,

@@ -68,6 +68,28 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_step_sens(const DevParams P, c
 #endif
 }
 
+// x_dot = f(x, u) with Fx = df/dx, Fu = df/du through the surrogate: ONE evaluation of the 6-slab engine (value + five
+// input tangents) and the dual rigid-body arithmetic on the same lanes — the first stage of k_nn_step_sens on its own.
+template <int WT, bool USE_MFMA>
+__global__ __launch_bounds__(kBlock, 1) void k_nn_deriv_sens(const DevParams P, const MlpPlan plan,
+                                                             const float* __restrict__ blob,
+                                                             const float* __restrict__ X, const float* __restrict__ U,
+                                                             long n, long blk, float* __restrict__ Xdot,
+                                                             float* __restrict__ Fx, float* __restrict__ Fu) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MlpEngine<6, WT, USE_MFMA> eng(plan, blob, smem);
+    eng.load_weights();
+    const WaveUnit w(n, blk);
+    float xv[13], uv[7];
+    load_rows<13>(X, w.ua, xv);
+    load_rows<7>(U, w.ua, uv);
+    Dual<4> k[13];
+    MlpCoeffs<MlpEngine<6, WT, USE_MFMA>> coeffs(eng);
+    deriv_seeded<4>(P, coeffs, w.g, xv, uv, k);
+    eng.drain();
+    if (w.live) deriv_store<4, false>(w.g, w.ua, k, Xdot, Fx, Fu);
+}
+
 // The sensitivity step for a REMAINDER of units that would leave the last round of the grid half empty: a wave's time
 // is set by its slab count, not by its live columns, so a unit group (16 units) is given to a PAIR of waves — one
 // carries the value slab and tangents 0-2, the other the value slab and tangents 3-4 — and a workgroup holds two

@@ -661,6 +661,84 @@ int ac_shoot_sens_f32(ac_handle* h, const float* X, const float* U, float dt, co
     return sens_impl(h, X, U, dt, dt_per_unit, B * H, B, Xn, A, Bm, c, stream);
 }
 
+// ---- x_dot with df/dx, df/du; envelope rows; quaternion rows (control/base.py:282-304, control/aircraft.py:44-59) ----
+static int deriv_sens_impl(ac_handle* h, const float* X, const float* U, long n, long blk, float* Xdot, float* Fx,
+                           float* Fu, void* stream) {
+    AC_ENTER(h);
+    if (h && n == 0) return AC_OK;
+    if (!h || !X || !U || !Xdot || !Fx || !Fu || n < 0 || blk <= 0) return AC_ERR_BAD_ARG;
+    int rc = model_ready(h);
+    if (rc != AC_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (h->dp.p.model_kind == AC_MODEL_NN) {
+        const int grid = (int)((n + 63) / 64);
+        bool launched = false;
+        AC_NN_CASE(2, true, (k_nn_deriv_sens<2, true>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
+        AC_NN_CASE(4, true, (k_nn_deriv_sens<4, true>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
+        AC_NN_CASE(8, true, (k_nn_deriv_sens<8, true>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
+        AC_NN_CASE(2, false, (k_nn_deriv_sens<2, false>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
+        AC_NN_CASE(4, false, (k_nn_deriv_sens<4, false>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
+        AC_NN_CASE(8, false, (k_nn_deriv_sens<8, false>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
+        if (!launched) return fail(AC_ERR_UNSUPPORTED, "no kernel instance for this MLP width / flavour");
+        note_launch(h, "k_nn_deriv_sens", grid, kBlock, h->plan.lds_total);
+        AC_HIP(hipGetLastError());
+        return AC_OK;
+    }
+    const int upb = 16 * (h->dp.p.model_kind == AC_MODEL_POLY ? AnalyticSensN<AC_MODEL_POLY>::value : AnalyticSensN<AC_MODEL_DEFAULT>::value);
+    const int grid = (int)((n + upb - 1) / upb);
+    AC_LAUNCH_ANALYTIC(k_deriv_sens, grid, kBlock, X, U, n, blk, Xdot, Fx, Fu);
+    note_launch(h, "k_deriv_sens", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_state_derivative_sens_f32(ac_handle* h, const float* X, const float* U, long n, float* Xdot, float* Fx, float* Fu,
+                                 void* stream) {
+    return deriv_sens_impl(h, X, U, n, n > 0 ? n : 1, Xdot, Fx, Fu, stream);
+}
+
+int ac_shoot_derivative_sens_f32(ac_handle* h, const float* X, const float* U, long B, long H, float* Xdot, float* Fx,
+                                 float* Fu, void* stream) {
+    if (B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    return deriv_sens_impl(h, X, U, B * H, B > 0 ? B : 1, Xdot, Fx, Fu, stream);
+}
+
+static int envelope_impl(ac_handle* h, const float* X, long n, long blk, float* rows, float* Jx, void* stream) {
+    AC_ENTER(h);
+    if (h && n == 0) return AC_OK;
+    if (!h || !X || !rows || n < 0 || blk <= 0) return AC_ERR_BAD_ARG;
+    if (h->dp.p.model_kind == AC_MODEL_QUAD) return fail(AC_ERR_UNSUPPORTED, "envelope rows are the fixed-wing plugin's (control/aircraft.py)");
+    const int grid = (int)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_envelope<0>, grid, kBlock, 0, (hipStream_t)stream, h->dp, X, n, blk, rows, Jx);
+    note_launch(h, "k_envelope", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_envelope_f32(ac_handle* h, const float* X, long n, float* rows, float* Jx, void* stream) {
+    return envelope_impl(h, X, n, n > 0 ? n : 1, rows, Jx, stream);
+}
+
+int ac_shoot_envelope_f32(ac_handle* h, const float* X, long B, long H, float* rows, float* Jx, void* stream) {
+    if (B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    return envelope_impl(h, X, B * H, B > 0 ? B : 1, rows, Jx, stream);
+}
+
+int ac_quat_rows_f32(ac_handle* h, int mode, const float* X, const float* Xdot, const float* Fx, const float* Fu, long B,
+                     long H, float* row, float* Jx, float* Ju, void* stream) {
+    AC_ENTER(h);
+    if (B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    const long n = B * H;
+    if (h && n == 0) return AC_OK;
+    if (!h || !X || !row || !Jx || !Ju || (mode != 0 && mode != 1)) return AC_ERR_BAD_ARG;
+    if (mode == 1 && (!Xdot || !Fx || !Fu)) return AC_ERR_BAD_ARG;
+    const int grid = (int)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_quat_rows<0>, grid, kBlock, 0, (hipStream_t)stream, X, Xdot, Fx, Fu, n, B, mode, row, Jx, Ju);
+    note_launch(h, "k_quat_rows", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
 // ---- second-order step sensitivities ---------------------------------------------------------------
 static int hess_impl(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, const float* Lam,
                      long n, long blk, float* Hout, void* stream) {

@@ -20,6 +20,12 @@ from .coefficient_models import COEFF_MODEL_REGISTRY, CoefficientModel, DefaultM
 __all__ = ["Aircraft", "AircraftOpts"]
 
 
+def _torch_mod():
+    import torch
+
+    return torch
+
+
 @dataclass
 class AircraftOpts(SixDOFOpts):
     """reference dynamics/aircraft.py:22-38"""
@@ -103,6 +109,29 @@ class Aircraft(SixDOF):
 
     def _install_model(self) -> None:
         self.coefficient_model.install(self._handle)
+
+    # ---- flight envelope (reference control/aircraft.py:44-59) ------------------------------------------------------
+    ENVELOPE_BOUNDS = ((20.0 ** 2, 100.0 ** 2), (-float(np.deg2rad(10)), float(np.deg2rad(10))),
+                       (-float(np.deg2rad(20)), float(np.deg2rad(20))), (-float("inf"), 0.0))
+
+    def envelope(self, x, want_jacobian: bool = True):
+        """Rows of AircraftControl.state_constraint for a column batch x (13, n): rows (4, n) = (|v_rel|^2, beta, alpha, z),
+        bounded by ENVELOPE_BOUNDS, and their state Jacobian Jx (4, 13, n) (None if not wanted)."""
+        torch = _torch_mod()
+        lib = self._sync()
+        X, npx, vec = self._in(x, self.num_states, "x")
+        n = X.shape[1]
+        rows = torch.empty((4, n), device=X.device, dtype=torch.float32)
+        Jx = torch.empty((4, 13, n), device=X.device, dtype=torch.float32) if want_jacobian else None
+        _lib.check(lib.ac_envelope_f32(self._handle, X.data_ptr(), n, rows.data_ptr(),
+                                       Jx.data_ptr() if Jx is not None else None, self._stream()), "ac_envelope_f32")
+        if npx:
+            rows = rows.cpu().numpy().astype(np.float64)
+            Jx = None if Jx is None else Jx.cpu().numpy().astype(np.float64)
+        if vec:
+            rows = rows[..., 0]
+            Jx = None if Jx is None else Jx[..., 0]
+        return rows, Jx
 
     # what the test oracle needs to rebuild the same airframe (tests only)
     def airframe_dict(self) -> dict:

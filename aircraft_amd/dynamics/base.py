@@ -283,6 +283,34 @@ class SixDOF(ABC):
             c = None if c is None else c[..., 0]
         return Xn, A, Bm, c
 
+    def state_derivative_sens(self, x, u, out=None):
+        """(x_dot, Fx, Fu): f(x, u) with Fx = df/dx (13,13,n) and Fu = df/du (13,7,n) — `ca.jacobian(state_derivative, .)`,
+        which the reference's implicit defect row and Baumgarte row (control/base.py:282-304) and its LQR wrapper
+        (dynamics/base.py:51-52) differentiate."""
+        lib = self._sync()
+        torch = _torch()
+        X, npx, vec = self._in(x, self.num_states, "x")
+        U, _, _ = self._in_u(u)
+        n = X.shape[1]
+        if U.shape[1] != n:
+            raise ValueError("x and u must have the same number of columns")
+        ns, nc = self.num_states, _lib.NUM_CONTROLS
+        fresh = out is None
+        if out is None:
+            out = (torch.empty_like(X), torch.empty((ns, ns, n), device=X.device, dtype=torch.float32),
+                   torch.empty((ns, nc, n), device=X.device, dtype=torch.float32))
+        Xd, Fx, Fu = out
+        _lib.check(lib.ac_state_derivative_sens_f32(self._handle, X.data_ptr(), U.data_ptr(), n, Xd.data_ptr(),
+                                                    Fx.data_ptr(), Fu.data_ptr(), self._stream()),
+                   "ac_state_derivative_sens_f32")
+        if npx:
+            Xd, Fx, Fu = (t.cpu().numpy().astype(np.float64) for t in (Xd, Fx, Fu))
+        if fresh and self.num_controls < nc:
+            Fu = Fu[:, : self.num_controls]
+        if vec:
+            Xd, Fx, Fu = Xd[..., 0], Fx[..., 0], Fu[..., 0]
+        return Xd, Fx, Fu
+
     def step_hess(self, x, u, dt, lam, out=None):
         """Hessian of lam . F(x, u, dt) over z = (x[13], u[7], dt): (21, 21, n) — the block the defect rows contribute to
         the Lagrangian Hessian IPOPT evaluates as `nlp_hess_l` (control/base.py:279-280; todo.md:102).

@@ -132,6 +132,33 @@ int ac_shoot_step_f32(ac_handle* h, const float* X, const float* U, float dt, co
 int ac_shoot_sens_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long B,
                       long H, float* Xn, float* A, float* Bm, float* c, void* stream);
 
+/* x_dot = f(x, u) with its Jacobians Fx = df/dx [13][13][n], Fu = df/du [13][7][n] — ca.jacobian(state_derivative, .):
+ * the implicit defect row  x_{k+1} - x_k - dt_k f(x_{k+1}, u_k)  (control/base.py:282-284), the Baumgarte row (:288-304)
+ * and the LQR wrapper (dynamics/base.py:51-52) differentiate f, not the step.  df/dp = 0 and df/d(thrust) = 0 exactly.
+ * ac_shoot_derivative_sens_f32 reads H nodes of rollout-shaped X [>=H][13][B], U [H][7][B] in place (pass X + 13 B to
+ * evaluate at the NEXT nodes x_1..x_H with the controls u_0..u_{H-1}) and writes Xdot [H][13][B], Fx [H][13][13][B],
+ * Fu [H][13][7][B]. */
+int ac_state_derivative_sens_f32(ac_handle* h, const float* X, const float* U, long n, float* Xdot, float* Fx, float* Fu,
+                                 void* stream);
+int ac_shoot_derivative_sens_f32(ac_handle* h, const float* X, const float* U, long B, long H, float* Xdot, float* Fx,
+                                 float* Fu, void* stream);
+
+/* Envelope rows of AircraftControl.state_constraint (control/aircraft.py:44-59) and their state Jacobian:
+ *   rows[0] = v_rel . v_rel   (bounded 20^2 .. 100^2)        rows[1] = beta   (|.| <= 10 deg)
+ *   rows[2] = alpha           (|.| <= 20 deg)                rows[3] = z = x[2]   (< 0)
+ * rows [4][n]; Jx = d rows / dx [4][13][n] (may be NULL).  The rows do not depend on the control.  Shooting form:
+ * X [>=H][13][B] in place -> rows [H][4][B], Jx [H][4][13][B].  Fixed-wing plugin only (AC_ERR_UNSUPPORTED for the quadrotor). */
+int ac_envelope_f32(ac_handle* h, const float* X, long n, float* rows, float* Jx, void* stream);
+int ac_shoot_envelope_f32(ac_handle* h, const float* X, long B, long H, float* rows, float* Jx, void* stream);
+
+/* Quaternion rows of ControlProblem.state_constraint on H nodes of X [>=H][13][B] (control/base.py:285-304):
+ *   mode 0 ('constraint'):  row = q . q - 1                                                        (:285-286)
+ *   mode 1 ('baumgarte'):   row = 2 a phi_dot + b^2 phi,  phi = q . q - 1,  phi_dot = 2 q . q_dot,  a = b = 2   (:288-304)
+ * row [H][B], Jx = d row / dx [H][13][B], Ju = d row / du [H][7][B].  Mode 1 needs Xdot, Fx, Fu of the same (x, u) from
+ * ac_shoot_derivative_sens_f32 (NULL allowed in mode 0). */
+int ac_quat_rows_f32(ac_handle* h, int mode, const float* X, const float* Xdot, const float* Fx, const float* Fu, long B,
+                     long H, float* row, float* Jx, float* Ju, void* stream);
+
 /* Second-order step sensitivities: Hout [21][21][n] = sum_i lambda_i d2F_i / dz dz over z = (x[13], u[7], dt) — the
  * block the defect rows x_{k+1} - F(x_k, u_k, dt_k) (control/base.py:279-280) contribute to IPOPT's `nlp_hess_l`
  * (the reference's largest time sink, todo.md:102).  lambda [13][n] (device) are the multipliers of the 13 rows of F.

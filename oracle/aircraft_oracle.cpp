@@ -503,6 +503,57 @@ int oracle_step_sens_f64(const oracle_params* p, const double* X, const double* 
     return 0;
 }
 
+// x_dot = f(x, u) with its Jacobians Fx = df/dx (13x13), Fu = df/du (13x7): what ca.jacobian(state_derivative, .) gives
+// the reference — the implicit defect row x_k + dt f(x_{k+1}, u_k) (control/base.py:282-284), the Baumgarte row
+// (:288-304) and the LQR wrapper (dynamics/base.py:51-52) differentiate f, not the step.
+int oracle_state_derivative_sens_f64(const oracle_params* p, const double* X, const double* U, long n, double* Xdot,
+                                     double* Fx, double* Fu) {
+    if (!p || !X || !U || !Xdot || n < 0) return -1;
+    Derived D; make_derived(*p, D);
+    typedef Dual<20> T;  // 13 state + 7 control directions
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) {
+        double xv[13], uv[7];
+        gather(X, n, i, 13, xv); gather(U, n, i, 7, uv);
+        T x[13], u[7], xd[13];
+        for (int r = 0; r < 13; ++r) { x[r] = T(xv[r]); x[r].d[r] = 1.0; }
+        for (int r = 0; r < 7; ++r) { u[r] = T(uv[r]); u[r].d[13 + r] = 1.0; }
+        state_derivative<T>(*p, D, x, u, xd);
+        for (int r = 0; r < 13; ++r) {
+            Xdot[(long)r * n + i] = xd[r].v;
+            if (Fx) for (int j = 0; j < 13; ++j) Fx[((long)r * 13 + j) * n + i] = xd[r].d[j];
+            if (Fu) for (int j = 0; j < 7; ++j) Fu[((long)r * 7 + j) * n + i] = xd[r].d[13 + j];
+        }
+    }
+    return 0;
+}
+
+// Envelope rows of AircraftControl.state_constraint (control/aircraft.py:44-59) and their state Jacobian:
+//   rows[0] = v_rel . v_rel   (bounded 20^2 .. 100^2)      rows[1] = beta   (|.| <= 10 deg)
+//   rows[2] = alpha           (|.| <= 20 deg)              rows[3] = z = x[2]  (< 0)
+// rows [4][n], Jx [4][13][n] (may be NULL).  The rows do not depend on the control.
+int oracle_envelope_f64(const oracle_params* p, const double* X, long n, double* rows, double* Jx) {
+    if (!p || !X || !rows || n < 0) return -1;
+    Derived D; make_derived(*p, D);
+    typedef Dual<13> T;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) {
+        double xv[13];
+        gather(X, n, i, 13, xv);
+        T x[13], u[7];
+        for (int r = 0; r < 13; ++r) { x[r] = T(xv[r]); x[r].d[r] = 1.0; }
+        for (int r = 0; r < 7; ++r) u[r] = T(0.0);
+        Aero<T> a;
+        aero<T>(*p, D, x, u, a);
+        const T row[4] = {a.vr[0] * a.vr[0] + a.vr[1] * a.vr[1] + a.vr[2] * a.vr[2], a.beta, a.alpha, x[2]};
+        for (int r = 0; r < 4; ++r) {
+            rows[(long)r * n + i] = row[r].v;
+            if (Jx) for (int j = 0; j < 13; ++j) Jx[((long)r * 13 + j) * n + i] = row[r].d[j];
+        }
+    }
+    return 0;
+}
+
 int oracle_aero_f64(const oracle_params* p, const double* X, const double* U, long n, double* out) {
     if (!p || !X || !U || !out || n < 0) return -1;
     Derived D; make_derived(*p, D);

@@ -77,6 +77,12 @@ int oracle_step_sens_f64(const oracle_params* p, const double* X, const double* 
 /* Getters: out [22][n] = v_frd_rel(3), airspeed, alpha, beta, qbar, coefficients(6), forces_frd(3),
  * moments_frd(3), phi, theta, psi   — dynamics/base.py:147-278, aircraft.py:255-330, base.py:179-195 */
 int oracle_aero_f64(const oracle_params* p, const double* X, const double* U, long n, double* out);
+/* x_dot with Fx = df/dx [13][13][n], Fu = df/du [13][7][n] (either may be NULL) — ca.jacobian(state_derivative, .):
+ * control/base.py:282-304 (implicit and Baumgarte rows), dynamics/base.py:51-52 (LQR). */
+int oracle_state_derivative_sens_f64(const oracle_params* p, const double* X, const double* U, long n, double* Xdot,
+                                     double* Fx, double* Fu);
+/* envelope rows [4][n] = (|v_rel|^2, beta, alpha, z) of control/aircraft.py:44-59 and Jx [4][13][n] (may be NULL) */
+int oracle_envelope_f64(const oracle_params* p, const double* X, long n, double* rows, double* Jx);
 
 /* Coefficient MLP alone: inputs [n][5] row-major -> outputs [n][6], jac [n][6][5] (may be NULL)
  *   — ScaledModel.forward, surrogates/models.py:143-155 (no rudder term). */

@@ -66,6 +66,10 @@ def lib():
         L.oracle_step_sens_f64.argtypes = [pp, dp, dp, dp, C.c_int, C.c_long, dp, dp, dp, dp]
         L.oracle_aero_f64.argtypes = [pp, dp, dp, C.c_long, dp]
         L.oracle_mlp_f64.argtypes = [pp, dp, C.c_long, dp, dp]
+        L.oracle_state_derivative_sens_f64.argtypes = [pp, dp, dp, C.c_long, dp, dp, dp]
+        L.oracle_state_derivative_sens_f64.restype = C.c_int
+        L.oracle_envelope_f64.argtypes = [pp, dp, C.c_long, dp, dp]
+        L.oracle_envelope_f64.restype = C.c_int
         L.oracle_num_threads.restype = C.c_int
         L.oracle_set_num_threads.argtypes = [C.c_int]
         for f in ("oracle_state_derivative_f64", "oracle_step_f64", "oracle_rollout_f64", "oracle_step_sens_f64",
@@ -168,6 +172,21 @@ class Oracle:
         assert lib().oracle_step_sens_f64(C.byref(self.p), _dptr(X), _dptr(U), _dptr(dta), sc, n, _dptr(Xn), _dptr(A),
                                           _dptr(Bm), _dptr(c)) == 0
         return Xn, A, Bm, c
+
+    def state_derivative_sens(self, X, U):
+        """(x_dot (13,n), Fx = df/dx (13,13,n), Fu = df/du (13,7,n)) by exact forward-mode AD"""
+        X = _c64(X); U = _c64(U); n = X.shape[1]
+        xd = np.empty((13, n)); Fx = np.empty((13, 13, n)); Fu = np.empty((13, 7, n))
+        assert lib().oracle_state_derivative_sens_f64(C.byref(self.p), _dptr(X), _dptr(U), n, _dptr(xd), _dptr(Fx),
+                                                      _dptr(Fu)) == 0
+        return xd, Fx, Fu
+
+    def envelope(self, X):
+        """(rows (4,n) = |v_rel|^2, beta, alpha, z ; Jx (4,13,n)) — control/aircraft.py:44-59"""
+        X = _c64(X); n = X.shape[1]
+        rows = np.empty((4, n)); Jx = np.empty((4, 13, n))
+        assert lib().oracle_envelope_f64(C.byref(self.p), _dptr(X), n, _dptr(rows), _dptr(Jx)) == 0
+        return rows, Jx
 
     AERO_ROWS = {"v_frd_rel": slice(0, 3), "airspeed": 3, "alpha": 4, "beta": 5, "qbar": 6,
                  "coefficients": slice(7, 13), "forces_frd": slice(13, 16), "moments_frd": slice(16, 19),

@@ -200,3 +200,44 @@ def test_quadrotor_known_answers_and_sensitivities():
     assert not Bm[:, 4:].any()
     fd = (o2.state_update(X, U, 0.02 + h) - o2.state_update(X, U, 0.02 - h)) / (2 * h)
     assert np.abs(c - fd).max() < 1e-6
+
+
+@pytest.mark.parametrize("model,hidden", [("default", None), ("poly", None), ("linear", None), ("nn", None), ("nn", (64, 64, 64))])
+def test_state_derivative_jacobians_match_finite_differences(model, hidden):
+    """Fx = df/dx, Fu = df/du (exact forward-mode AD of the pinned f) against central differences of f itself —
+    what the implicit defect row and the Baumgarte row of control/base.py:282-304 differentiate."""
+    o = make_oracle(make_aircraft(model, hidden=hidden, stall_scaling=True))
+    X, U = synthetic_units(40, seed=23, flaps=True)
+    xd, Fx, Fu = o.state_derivative_sens(X, U)
+    assert np.array_equal(xd, o.state_derivative(X, U))
+    assert not Fx[:, :3].any() and np.array_equal(Fx[:3, 3:6], np.broadcast_to(np.eye(3)[:, :, None], (3, 3, 40)))
+    assert not Fu[:, 3:6].any()  # thrust has no effect in the reference's force model (aircraft.py:320)
+    hs = np.array([1e-3] * 3 + [1e-4] * 3 + [1e-6] * 4 + [1e-5] * 3)
+    for j in range(13):
+        d = np.zeros_like(X); d[j] = hs[j]
+        fd = (o.state_derivative(X + d, U) - o.state_derivative(X - d, U)) / (2 * hs[j])
+        assert np.abs(fd - Fx[:, j]).max() <= 2e-6 * max(np.abs(Fx[:, j]).max(), 1.0), j
+    for j in (0, 1, 2, 6):
+        d = np.zeros_like(U); d[j] = 1e-4
+        fd = (o.state_derivative(X, U + d) - o.state_derivative(X, U - d)) / 2e-4
+        assert np.abs(fd - Fu[:, j]).max() <= 2e-6 * max(np.abs(Fu[:, j]).max(), 1.0), j
+
+
+def test_envelope_rows_and_jacobian():
+    """The rows of AircraftControl.state_constraint (control/aircraft.py:44-59) = the getters, and their state Jacobian
+    against central differences."""
+    o = make_oracle(make_aircraft("poly"))
+    X, U = synthetic_units(60, seed=29)
+    rows, Jx = o.envelope(X)
+    a = o.aero(X, U)
+    assert np.array_equal(rows[0], (a[0:3] ** 2).sum(axis=0)) and np.array_equal(rows[1], a[5])
+    assert np.array_equal(rows[2], a[4]) and np.array_equal(rows[3], X[2])
+    assert np.array_equal(Jx[3], np.broadcast_to(np.eye(13)[2][:, None], (13, 60)))  # dz/dx
+    assert not Jx[:3, :3].any() and not Jx[:3, 10:].any()  # no dependence on position / body rates
+    hs = np.array([1e-3] * 3 + [1e-4] * 3 + [1e-6] * 4 + [1e-5] * 3)
+    for j in range(3, 10):
+        d = np.zeros_like(X); d[j] = hs[j]
+        fd = (o.envelope(X + d)[0] - o.envelope(X - d)[0]) / (2 * hs[j])
+        assert np.abs(fd - Jx[:, j]).max() <= 2e-6 * max(np.abs(Jx[:, j]).max(), 1.0), j
+    # synthetic units are inside the envelope (SURVEY §8d)
+    assert (rows[0] >= 400).all() and (rows[0] <= 1e4).all() and (np.abs(rows[1]) <= np.deg2rad(10)).all()
