@@ -1,0 +1,315 @@
+// ac_mlp_valu.hpp — the MLP surrogate on the VECTOR ALUs: "MFMA off", BASELINE configs[1] (cfg2: 3x64).
+//
+// A wave evaluates the network for 16 units x 6 slabs (value + five input tangents) = 96 rows as a register-tiled fp32
+// GEMM per layer on v_pk_fma_f32, with no cross-lane operation in the inner loop:
+//   * lane (i, j), i = lane >> 3, j = lane & 7, owns the 12 rows of units i and i + 8 (all six slabs of a unit sit in ONE
+//     lane, so the tanh / (1 - h^2) epilogue is lane-local) and width / 8 of the layer's output neurons: 12 x 8
+//     accumulators at width 64;
+//   * per 4-deep k-step the lane reads its 12 activation rows (12 ds_read_b128) and its 8 weight columns (8 ds_read_b128)
+//     from LDS and issues 192 v_pk_fma_f32 — one LDS read per 9.6 packed FMAs (tools/micro/valu_pkfma_sgpr.hip measured
+//     why it is a tile and not a lane-per-neuron or lane-per-unit layout: every weight that has to reach all 64 lanes costs
+//     an LDS read (~14 wave cycles per 4 weights) or a scalar load whose latency one 102-SGPR wave cannot cover);
+//   * activations live in an LDS buffer of the wave's own, [96 rows][width + 4] floats — the +4 padding spreads the eight
+//     row groups over distinct banks — written by the epilogue of one layer and read as the operand of the next;
+//     the whole weight image (36 KB for 3 x 64) is resident in LDS;
+//   * the rigid-body / RK4 / dual arithmetic around it is the SAME code as the matrix-core kernels' (16 units x 4 lanes,
+//     Dual<4>): the engine presents the same forward(z, y, J) interface as MlpEngine.
+// Hidden widths <= 64 (the activation buffers of four waves and the weights must fit 160 KB of LDS) and at least two
+// layers after the host-side fold; other nets keep the cross-lane validation path of ac_mlp.hpp.
+#pragma once
+#include "ac_kernels_nn.hpp"
+
+namespace ac {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct ValuPlan {
+    int n_layers;                 // >= 2 (after the fold); layer 0: 8 (5 padded) -> W, hidden: W -> W, last: W -> 8 (6 padded)
+    int act_last;                 // tanh on the last layer?
+    int w_off[AC_MAX_LAYERS];     // float offset of the layer's weights in the image: [K][N] row-major (k-major) for all
+                                  // layers but the last, which is stored transposed [8][K]
+    int b_off[AC_MAX_LAYERS];     // float offset of the bias (N floats, zero padded)
+    int image_floats;             // padded to a multiple of 256 (whole 1-KiB LDS-DMA pieces)
+};
+
+// acc.xy += a.{lo|hi} (broadcast) * w.xy
+AC_DI void pk_fma_alo(f32x2& acc, const f32x2& a, const f32x2& w) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(a), "v"(w));
+}
+AC_DI void pk_fma_ahi(f32x2& acc, const f32x2& a, const f32x2& w) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(w));
+}
+// acc.xy += a.xy * w.xy (two k-steps at once: the last layer's k-pair partial sums)
+AC_DI void pk_fma_pair(f32x2& acc, const f32x2& a, const f32x2& w) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(w));
+}
+
+template <int WIDTH> struct MlpEngineTiled {
+    static_assert(WIDTH == 32 || WIDTH == 64, "hidden width padded to 32 or 64");
+    static constexpr bool kTangent = true;
+    static constexpr int kTangents = 5;
+    static constexpr int S = WIDTH + 4;       // activation row stride in floats (6 S mod 64 = 24: eight distinct bank groups)
+    static constexpr int kRows = 96;          // 16 units x 6 slabs
+    static constexpr int kBufFloats = kRows * S;
+    static constexpr int kWaves = 4;
+    static constexpr int NB = WIDTH / 8;      // output neurons per lane (8 lane columns): 8 at width 64, 4 at width 32
+    static constexpr int NP = NB / 2;         // ... as packed pairs
+    static constexpr int NQ = NB / 4;         // ... as 16-byte LDS accesses
+
+    const ValuPlan& plan;
+    const float* wimg;   // LDS: weight image
+    float* act;          // LDS: this wave's activation buffer [96][S]
+    int lane, g, col, ti, tj;
+    Stamper st;
+
+    static AC_DI int lds_bytes(const ValuPlan& pl) { return pl.image_floats * 4 + kWaves * kBufFloats * 4; }
+
+    AC_DI MlpEngineTiled(const ValuPlan& pl, const float* blob, char* lds_base) : plan(pl) {
+        lane = threadIdx.x & 63; g = lane >> 4; col = lane & 15; ti = lane >> 3; tj = lane & 7;
+        wimg = reinterpret_cast<const float*>(lds_base);
+        act = reinterpret_cast<float*>(lds_base) + pl.image_floats + (threadIdx.x >> 6) * kBufFloats;
+        gimg = blob;
+        lds0 = lds_base;
+    }
+    const float* gimg;
+    char* lds0;
+
+    AC_DI void load_weights() {
+        lds_dma_copy(gimg, lds0, plan.image_floats * 4, threadIdx.x >> 6, blockDim.x >> 6, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    AC_DI void drain() {}
+
+    // row of (local unit u in {0, 1} of this lane, slab s): units ti and ti + 8
+    AC_DI int row_of(int u, int s) const { return (ti + 8 * u) * 6 + s; }
+
+    // LDS ordering inside the wave: the LDS executes one wave's operations in issue order; the fence keeps the compiler
+    // from moving a read of another lane's data above the write that produced it.
+    AC_DI static void wave_sync() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // acc[12 rows][NP neuron pairs] += A[rows][k0 .. k0+3] * W[k0 .. k0+3][NB tj .. NB tj + NB - 1]
+    template <int N>
+    AC_DI void kstep(f32x2 (&acc)[12][NP], const float* __restrict__ w, int k0) const {
+        f32x4 a[12], wv[4][NQ];
+#pragma unroll
+        for (int r = 0; r < 12; ++r)
+            a[r] = *reinterpret_cast<const f32x4*>(act + row_of(r / 6, r % 6) * S + k0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int h = 0; h < NQ; ++h)
+                wv[kk][h] = *reinterpret_cast<const f32x4*>(w + (k0 + kk) * N + NB * tj + 4 * h);
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            const f32x2 a01 = {a[r][0], a[r][1]}, a23 = {a[r][2], a[r][3]};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const f32x2 wp = {wv[kk][p >> 1][2 * (p & 1)], wv[kk][p >> 1][2 * (p & 1) + 1]};
+                    if (kk == 0) pk_fma_alo(acc[r][p], a01, wp);
+                    else if (kk == 1) pk_fma_ahi(acc[r][p], a01, wp);
+                    else if (kk == 2) pk_fma_alo(acc[r][p], a23, wp);
+                    else pk_fma_ahi(acc[r][p], a23, wp);
+                }
+            }
+        }
+    }
+
+    // bias + tanh on the value row, (1 - h^2) scaling on the five tangent rows of the same unit, all in this lane; then
+    // the 12 x 8 results go back to the activation buffer as the next layer's operand
+    template <bool TANH>
+    AC_DI void epilogue_store(f32x2 (&acc)[12][NP], const float* __restrict__ bias) {
+        float b[NB];
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + NB * tj + 4 * h);
+            b[4 * h] = bq[0]; b[4 * h + 1] = bq[1]; b[4 * h + 2] = bq[2]; b[4 * h + 3] = bq[3];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float v = acc[6 * u][p][e] + b[2 * p + e];
+                    if (TANH) {
+                        const float h = act_tanh(v), sp = fmaf(-h, h, 1.0f);
+                        acc[6 * u][p][e] = h;
+#pragma unroll
+                        for (int s = 1; s < 6; ++s) acc[6 * u + s][p][e] *= sp;
+                    } else {
+                        acc[6 * u][p][e] = v;
+                    }
+                }
+            }
+        }
+        wave_sync();  // every lane is done reading this layer's operand rows before they are overwritten
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            float* dst = act + row_of(r / 6, r % 6) * S + NB * tj;
+#pragma unroll
+            for (int h = 0; h < NQ; ++h)
+                *reinterpret_cast<f32x4*>(dst + 4 * h) = f32x4{acc[r][2 * h][0], acc[r][2 * h][1], acc[r][2 * h + 1][0], acc[r][2 * h + 1][1]};
+        }
+        wave_sync();
+    }
+
+    template <int K> AC_DI void dense_layer(int l) {
+        f32x2 acc[12][NP];
+#pragma unroll
+        for (int r = 0; r < 12; ++r)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) acc[r][p] = f32x2{0.f, 0.f};
+        const float* w = wimg + plan.w_off[l];
+        if constexpr (K == 8) {
+            kstep<WIDTH>(acc, w, 0);
+            kstep<WIDTH>(acc, w, 4);
+        } else {
+#pragma nounroll
+            for (int k0 = 0; k0 < K; k0 += 4) kstep<WIDTH>(acc, w, k0);
+        }
+        epilogue_store<true>(acc, wimg + plan.b_off[l]);  // tanh on every layer but the last (ac_set_mlp folds the others)
+    }
+
+    // Last layer, WIDTH -> 6 (padded 8): lane (i, j) computes output neuron j of its 12 rows; the packed FMA runs over
+    // k-pairs (even / odd partial sums) against the transposed weights Wt[j][k].
+    AC_DI void last_layer(int l) {
+        const float* wt = wimg + plan.w_off[l] + tj * WIDTH;
+        f32x2 acc[12];
+#pragma unroll
+        for (int r = 0; r < 12; ++r) acc[r] = f32x2{0.f, 0.f};
+#pragma nounroll
+        for (int k0 = 0; k0 < WIDTH; k0 += 8) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + k0), w1 = *reinterpret_cast<const f32x4*>(wt + k0 + 4);
+#pragma unroll
+            for (int r = 0; r < 12; ++r) {
+                const float* ar = act + row_of(r / 6, r % 6) * S + k0;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar), a1 = *reinterpret_cast<const f32x4*>(ar + 4);
+                pk_fma_pair(acc[r], f32x2{a0[0], a0[1]}, f32x2{w0[0], w0[1]});
+                pk_fma_pair(acc[r], f32x2{a0[2], a0[3]}, f32x2{w0[2], w0[3]});
+                pk_fma_pair(acc[r], f32x2{a1[0], a1[1]}, f32x2{w1[0], w1[1]});
+                pk_fma_pair(acc[r], f32x2{a1[2], a1[3]}, f32x2{w1[2], w1[3]});
+            }
+        }
+        const float bj = wimg[plan.b_off[l] + tj];
+        float o[12];
+#pragma unroll
+        for (int r = 0; r < 12; ++r) o[r] = acc[r][0] + acc[r][1];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float v = o[6 * u] + bj;
+            if (plan.act_last) {
+                const float h = act_tanh(v), sp = fmaf(-h, h, 1.0f);
+                o[6 * u] = h;
+#pragma unroll
+                for (int s = 1; s < 6; ++s) o[6 * u + s] *= sp;
+            } else {
+                o[6 * u] = v;
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 12; ++r) act[row_of(r / 6, r % 6) * S + tj] = o[r];
+        wave_sync();
+    }
+
+    // y[6], J[6][5] of the raw network for normalised inputs z[5]; every lane of a unit (col, g = 0..3) passes the same z
+    // and receives the same outputs.  Wave-collective.
+    template <int JC> AC_DI void forward(const float z[5], float y[6], float (*J)[JC]) {
+        static_assert(JC >= 5, "J holds the five input tangents");
+        // operand rows of layer 0: slab 0 = (z, 0, 0, 0), slab s = unit vector e_{s-1}; lane group g writes slabs 2g, 2g + 1
+        AC_MARK(st, 1);
+        wave_sync();
+        if (g < 3) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int s = 2 * g + q;
+                float* dst = act + (col * 6 + s) * S;
+                f32x4 lo, hi;
+                if (s == 0) { lo = f32x4{z[0], z[1], z[2], z[3]}; hi = f32x4{z[4], 0.f, 0.f, 0.f}; }
+                else {
+                    lo = f32x4{s == 1 ? 1.f : 0.f, s == 2 ? 1.f : 0.f, s == 3 ? 1.f : 0.f, s == 4 ? 1.f : 0.f};
+                    hi = f32x4{s == 5 ? 1.f : 0.f, 0.f, 0.f, 0.f};
+                }
+                *reinterpret_cast<f32x4*>(dst) = lo;
+                *reinterpret_cast<f32x4*>(dst + 4) = hi;
+            }
+        }
+        wave_sync();
+        dense_layer<8>(0);
+        AC_MARK(st, 2);
+#pragma nounroll
+        for (int l = 1; l < plan.n_layers - 1; ++l) dense_layer<WIDTH>(l);
+        AC_MARK(st, 4);
+        last_layer(plan.n_layers - 1);
+        AC_MARK(st, 5);
+        // outputs: row 6 col + s, columns 0..5
+        const float* src = act + col * 6 * S;
+        const f32x4 y0 = *reinterpret_cast<const f32x4*>(src), y1 = *reinterpret_cast<const f32x4*>(src + 4);
+        y[0] = y0[0]; y[1] = y0[1]; y[2] = y0[2]; y[3] = y0[3]; y[4] = y1[0]; y[5] = y1[1];
+#pragma unroll
+        for (int s = 1; s < 6; ++s) {
+            const f32x4 j0 = *reinterpret_cast<const f32x4*>(src + s * S), j1 = *reinterpret_cast<const f32x4*>(src + s * S + 4);
+            J[0][s - 1] = j0[0]; J[1][s - 1] = j0[1]; J[2][s - 1] = j0[2]; J[3][s - 1] = j0[3];
+            J[4][s - 1] = j1[0]; J[5][s - 1] = j1[1];
+        }
+        wave_sync();
+        AC_MARK(st, 6);
+    }
+};
+
+// The fused step + sensitivities kernel on the vector ALUs: k_nn_step_sens with the tiled engine.
+template <int WIDTH>
+__global__ __launch_bounds__(kBlock, 1) void k_nn_step_sens_tiled(const DevParams P, const ValuPlan plan,
+                                                                  const float* __restrict__ blob,
+                                                                  const float* __restrict__ X, const float* __restrict__ U,
+                                                                  float dt, const float* __restrict__ dt_per_unit, long n,
+                                                                  long blk, float* __restrict__ Xn, float* __restrict__ A,
+                                                                  float* __restrict__ Bm, float* __restrict__ c) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MlpEngineTiled<WIDTH> eng(plan, blob, smem);
+    eng.load_weights();
+    const WaveUnit w(n, blk);
+    float xv[13], uv[7];
+    load_rows<13>(X, w.ua, xv);
+    load_rows<7>(U, w.ua, uv);
+    const float hv = dt_per_unit ? dt_per_unit[w.unit] : dt;
+    Dual<4> x[13];
+    MlpCoeffs<MlpEngineTiled<WIDTH>> coeffs(eng);
+    sens_update<4>(P, coeffs, w.g, w.col, w.ua, xv, uv, hv, x, A, Bm, c, w.live);
+    if (w.live) {
+        const UnitAddr uo = w.ua.late();
+        if (w.g == 0) {
+            float* p = Xn + uo.off(13);
+#pragma unroll
+            for (int i = 0; i < 13; ++i) p[(long)i * blk] = x[i].v;
+        }
+        SensIO::store(w.g, uo, x, A, Bm, c, true);
+    }
+}
+
+template <int WIDTH>
+__global__ __launch_bounds__(kBlock, 1) void k_nn_deriv_sens_tiled(const DevParams P, const ValuPlan plan,
+                                                                   const float* __restrict__ blob,
+                                                                   const float* __restrict__ X, const float* __restrict__ U,
+                                                                   long n, long blk, float* __restrict__ Xdot,
+                                                                   float* __restrict__ Fx, float* __restrict__ Fu) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    MlpEngineTiled<WIDTH> eng(plan, blob, smem);
+    eng.load_weights();
+    const WaveUnit w(n, blk);
+    float xv[13], uv[7];
+    load_rows<13>(X, w.ua, xv);
+    load_rows<7>(U, w.ua, uv);
+    Dual<4> k[13];
+    MlpCoeffs<MlpEngineTiled<WIDTH>> coeffs(eng);
+    deriv_seeded<4>(P, coeffs, w.g, xv, uv, k);
+    if (w.live) deriv_store<4, false>(w.g, w.ua, k, Xdot, Fx, Fu);
+}
+
+}  // namespace ac

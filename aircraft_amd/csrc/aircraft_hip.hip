@@ -71,6 +71,11 @@ struct ac_handle {
     int use_mfma;
     float* d_blob;  // packed MLP weights + biases (device)
     size_t blob_floats;
+    // "MFMA off" flavour on the tiled v_pk_fma_f32 engine (ac_mlp_valu.hpp): hidden widths <= 64, >= 2 layers
+    bool has_vplan;
+    ValuPlan vplan;
+    int vwidth;        // 32 or 64
+    float* d_vblob;    // weight image [layer][K][N] (+ biases), device
     float* d_hess_ws;  // [n][4][126] stage tensors of the MLP Hessian path, grown on demand
     size_t hess_ws_floats;
     float* d_track;  // [nseg][3][4] segment cubics (device)
@@ -229,6 +234,7 @@ int ac_destroy(ac_handle* h) {
     AC_ENTER(h);
     if (!h) return AC_ERR_BAD_ARG;
     if (h->d_blob) (void)hipFree(h->d_blob);
+    if (h->d_vblob) (void)hipFree(h->d_vblob);
     if (h->d_track) (void)hipFree(h->d_track);
     if (h->d_hess_ws) (void)hipFree(h->d_hess_ws);
     delete h;
@@ -384,10 +390,59 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
         for (int l = 0, i = 0; l < n_layers; ++l)
             if (pl.lds_off[l] < 0) pl.streamed[i++] = l;
     }
+    // "MFMA off": weight image of the tiled vector-ALU engine, k-major [K][N] per layer (the last layer transposed [8][K]),
+    // hidden widths zero-padded to 32 or 64.  Nets it does not cover (wider than 64, or a single layer after the fold)
+    // keep the cross-lane validation path.
+    ValuPlan vp;
+    memset(&vp, 0, sizeof(vp));
+    std::vector<float> vimg;
+    bool vok = !use_mfma && n_layers >= 2 && maxh <= 64;
+    const int vw = maxh <= 32 ? 32 : 64;
+    if (vok) {
+        vp.n_layers = n_layers;
+        vp.act_last = net[(size_t)n_layers - 1].act;
+        size_t off = 0;
+        for (int l = 0; l < n_layers; ++l) {
+            const bool last = l == n_layers - 1;
+            const int K = l == 0 ? 8 : vw, N = last ? 8 : vw;
+            vp.w_off[l] = (int)off; off += (size_t)K * N;
+            vp.b_off[l] = (int)off; off += (size_t)N;
+        }
+        vp.image_floats = (int)((off + 255) / 256 * 256);
+        vimg.assign((size_t)vp.image_floats, 0.f);
+        for (int l = 0; l < n_layers; ++l) {
+            const bool last = l == n_layers - 1;
+            const int nin = widths[l], nout = widths[l + 1], K = l == 0 ? 8 : vw, N = last ? 8 : vw;
+            float* wd = vimg.data() + vp.w_off[l];
+            for (int k = 0; k < nin; ++k)
+                for (int nn = 0; nn < nout; ++nn) {
+                    const float wv = fW[(size_t)l][(size_t)nn * nin + k];
+                    if (last) wd[(size_t)nn * K + k] = wv;   // Wt[j][k]
+                    else wd[(size_t)k * N + nn] = wv;        // W[k][n]
+                }
+            for (int nn = 0; nn < nout; ++nn) vimg[(size_t)vp.b_off[l] + nn] = fb[(size_t)l][(size_t)nn];
+        }
+        const int lds_need = vp.image_floats * 4 + 4 * 96 * (vw + 4) * 4;
+        if (lds_need > kLdsBudget) vok = false;
+    }
+    float* dv = nullptr;
+    if (vok) {
+        AC_HIP(hipMalloc(&dv, vimg.size() * sizeof(float)));
+        hipError_t ev = hipMemcpy(dv, vimg.data(), vimg.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (ev != hipSuccess) { (void)hipFree(dv); return hip_fail(ev, "hipMemcpy(valu image)"); }
+    }
     float* d = nullptr;
-    AC_HIP(hipMalloc(&d, total_floats * sizeof(float)));
+    {
+        hipError_t em = hipMalloc(&d, total_floats * sizeof(float));
+        if (em != hipSuccess) { if (dv) (void)hipFree(dv); return hip_fail(em, "hipMalloc(mlp blob)"); }
+    }
     hipError_t e = hipMemcpy(d, blob.data(), total_floats * sizeof(float), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "hipMemcpy(mlp blob)"); }
+    if (e != hipSuccess) { (void)hipFree(d); if (dv) (void)hipFree(dv); return hip_fail(e, "hipMemcpy(mlp blob)"); }
+    if (h->d_vblob) (void)hipFree(h->d_vblob);
+    h->d_vblob = dv;
+    h->has_vplan = vok;
+    h->vplan = vp;
+    h->vwidth = vw;
     if (h->d_blob) (void)hipFree(h->d_blob);
     h->d_blob = d;
     h->blob_floats = total_floats;
@@ -599,6 +654,23 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
         // MLP: 16 units per wave, 4 waves (64 units) per workgroup, one workgroup resident per CU — time goes in whole
         // rounds over the CUs.  A remainder of at most half a round is given to k_nn_step_sens_pair (two waves per 16
         // units, 32 units per workgroup, ~0.73 of a full workgroup's time) instead of paying a full round for it.
+        if (!h->use_mfma && h->has_vplan) {
+            // "MFMA off": the tiled v_pk_fma_f32 engine (ac_mlp_valu.hpp), 16 units per wave, 64 per workgroup
+            const int grid = (int)((n + 63) / 64);
+            const int lds = h->vplan.image_floats * 4 + 4 * 96 * (h->vwidth + 4) * 4;
+#define AC_TILED_SENS(W_)                                                                                          \
+            if (h->vwidth == W_) {                                                                                 \
+                auto kern = k_nn_step_sens_tiled<W_>;                                                              \
+                int rc_ = set_lds_limit(h, kern, lds);                                                             \
+                if (rc_ != AC_OK) return rc_;                                                                      \
+                hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->vplan, h->d_vblob, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c); \
+            }
+            AC_TILED_SENS(32) AC_TILED_SENS(64)
+#undef AC_TILED_SENS
+            note_launch(h, "k_nn_step_sens_tiled", grid, kBlock, lds);
+            AC_HIP(hipGetLastError());
+            return AC_OK;
+        }
         const long cus = h->num_cus > 0 ? h->num_cus : 256;
         const long per_round = 64 * cus;
         long n_main = n, n_pair = 0;
@@ -670,6 +742,22 @@ static int deriv_sens_impl(ac_handle* h, const float* X, const float* U, long n,
     int rc = model_ready(h);
     if (rc != AC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (h->dp.p.model_kind == AC_MODEL_NN && !h->use_mfma && h->has_vplan) {
+        const int grid = (int)((n + 63) / 64);
+        const int lds = h->vplan.image_floats * 4 + 4 * 96 * (h->vwidth + 4) * 4;
+#define AC_TILED_DS(W_)                                                                                            \
+        if (h->vwidth == W_) {                                                                                     \
+            auto kern = k_nn_deriv_sens_tiled<W_>;                                                                 \
+            int rc_ = set_lds_limit(h, kern, lds);                                                                 \
+            if (rc_ != AC_OK) return rc_;                                                                          \
+            hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->vplan, h->d_vblob, X, U, n, blk, Xdot, Fx, Fu); \
+        }
+        AC_TILED_DS(32) AC_TILED_DS(64)
+#undef AC_TILED_DS
+        note_launch(h, "k_nn_deriv_sens_tiled", grid, kBlock, lds);
+        AC_HIP(hipGetLastError());
+        return AC_OK;
+    }
     if (h->dp.p.model_kind == AC_MODEL_NN) {
         const int grid = (int)((n + 63) / 64);
         bool launched = false;

@@ -355,3 +355,30 @@ def test_controller_initialise_like_the_reference_driver(gpu):
     g2 = ms2.initialise(trim50, controls=np.zeros((7, 51)))
     ref2 = orc.rollout(f32_exact(trim50)[:, None], np.zeros((50, 7, 1)), 0.01)[:, :, 0].T
     assert block_rel_err(g2[:13], ref2) < STATE_TOL
+
+
+@pytest.mark.parametrize("hidden", [(64, 64, 64), (32, 32), None, (64,), (48, 24, 40)])
+@pytest.mark.parametrize("substeps", [1, 10])
+def test_valu_tiled_engine_step_sens(gpu, hidden, substeps):
+    """BASELINE cfg2 flavour ("MFMA off"): the tiled v_pk_fma_f32 engine (ac_mlp_valu.hpp) behind ac_step_sens_f32 for
+    nets of hidden width <= 64 — cfg2's 3x64, a 2x32, the reference's own net (5-32-6 after the fold), one hidden layer,
+    ragged widths — at a ragged batch, with per-unit dt, against the oracle AND against the matrix-core flavour."""
+    kw = dict(hidden=hidden, substeps=substeps, normalise=True, stall_scaling=True)
+    ac = make_aircraft("nn", use_mfma=False, **kw)
+    n = 333
+    X, U = synthetic_units(n, seed=37, flaps=True)
+    dt = f32_exact(np.random.default_rng(2).uniform(4e-3, 1e-2, n)) * (10 if substeps == 10 else 1)
+    Xn, A, Bm, c = ac.step_sens(dev(X, gpu), dev(U, gpu), dev(dt, gpu))
+    assert ac.last_launch()[0] == "k_nn_step_sens_tiled"
+    Xr, Ar, Br, cr = make_oracle(ac).step_sens(X, U, dt)
+    if substeps == 1:
+        assert block_rel_err(Xn.cpu().numpy(), Xr) < STATE_TOL
+        assert_sens(f"valu_tiled{hidden}", {"A": A, "B": Bm, "c": c}, {"A": Ar, "B": Br, "c": cr})
+    else:
+        ref, cond = conditioning(make_oracle(ac), X, U, dt, rollout=False)
+        check_against_conditioning(f"valu_tiled_update10{hidden}", Xn.cpu().numpy(), ref, cond, STATE_TOL, min_frac=0.9)
+    m = make_aircraft("nn", use_mfma=True, **kw)
+    Xm, Am, Bmm, cm = m.step_sens(dev(X, gpu), dev(U, gpu), dev(dt, gpu))
+    if substeps == 1:
+        assert block_rel_err(Xn.cpu().numpy(), Xm.cpu().numpy()) < 2e-6
+        assert unit_max_rel(A.cpu().numpy(), Am.cpu().numpy()).max() < 1e-5
