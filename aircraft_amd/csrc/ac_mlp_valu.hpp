@@ -91,18 +91,23 @@ template <int WIDTH> struct MlpEngineTiled {
         __builtin_amdgcn_wave_barrier();
     }
 
-    // acc[12 rows][NP neuron pairs] += A[rows][k0 .. k0+3] * W[k0 .. k0+3][NB tj .. NB tj + NB - 1]
-    template <int N>
-    AC_DI void kstep(f32x2 (&acc)[12][NP], const float* __restrict__ w, int k0) const {
-        f32x4 a[12], wv[4][NQ];
-#pragma unroll
-        for (int r = 0; r < 12; ++r)
-            a[r] = *reinterpret_cast<const f32x4*>(act + row_of(r / 6, r % 6) * S + k0);
+    // One 4-deep k-step:  acc[12 rows][NP neuron pairs] += A[rows][k0 .. k0+3] * W[k0 .. k0+3][NB tj .. NB tj + NB - 1].
+    // The weight fragment of a step is requested one step AHEAD (two register banks, the k loop unrolled by two), so only
+    // the activation rows are fetched in the step itself — and those are consumed one after the other, row r + 1 .. 11
+    // still in flight while row r computes (the LDS returns in issue order).
+    template <int N> AC_DI void load_w(f32x4 (&wv)[4][NQ], const float* __restrict__ w, int k0) const {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int h = 0; h < NQ; ++h)
                 wv[kk][h] = *reinterpret_cast<const f32x4*>(w + (k0 + kk) * N + NB * tj + 4 * h);
+    }
+    AC_DI void kstep(f32x2 (&acc)[12][NP], const f32x4 (&wv)[4][NQ], int k0) const {
+        f32x4 a[12];
+#pragma unroll
+        for (int r = 0; r < 12; ++r)
+            a[r] = *reinterpret_cast<const f32x4*>(act + row_of(r / 6, r % 6) * S + k0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 12; ++r) {
             const f32x2 a01 = {a[r][0], a[r][1]}, a23 = {a[r][2], a[r][3]};
@@ -118,6 +123,7 @@ template <int WIDTH> struct MlpEngineTiled {
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // bias + tanh on the value row, (1 - h^2) scaling on the five tangent rows of the same unit, all in this lane; then
@@ -166,12 +172,14 @@ template <int WIDTH> struct MlpEngineTiled {
 #pragma unroll
             for (int p = 0; p < NP; ++p) acc[r][p] = f32x2{0.f, 0.f};
         const float* w = wimg + plan.w_off[l];
-        if constexpr (K == 8) {
-            kstep<WIDTH>(acc, w, 0);
-            kstep<WIDTH>(acc, w, 4);
-        } else {
+        f32x4 wA[4][NQ], wB[4][NQ];
+        load_w<WIDTH>(wA, w, 0);
 #pragma nounroll
-            for (int k0 = 0; k0 < K; k0 += 4) kstep<WIDTH>(acc, w, k0);
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            load_w<WIDTH>(wB, w, k0 + 4);
+            kstep(acc, wA, k0);
+            load_w<WIDTH>(wA, w, k0 + 8 < K ? k0 + 8 : 0);  // (the last request is a harmless re-read of step 0)
+            kstep(acc, wB, k0 + 4);
         }
         epilogue_store<true>(acc, wimg + plan.b_off[l]);  // tanh on every layer but the last (ac_set_mlp folds the others)
     }
