@@ -268,8 +268,52 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
     // One Linear(+tanh) layer of static shape KT x NT tiles on all slabs.  wl: LDS address of the packed block.
     // The host pads every hidden width to 16*WT, so only the shapes <1,WT> (first), <WT,WT> (hidden),
     // <WT,1> (last) and <1,1> (single-layer net) occur.
+#ifdef AC_EXP_LAST2
+    // EXPERIMENT (not in the product build): the last layer (KT = WT, NT = 1) with two slabs' accumulator chains
+    // interleaved on shared A fragments — the shape of the round-1 experiment behind DESIGN §9.4.
+    template <int KT, int ACT>
+    AC_DI void layer_last2(const char* wl, int act) {
+        const f32x4* wf = reinterpret_cast<const f32x4*>(wl) + lane;
+        const f32x4* bias4 = reinterpret_cast<const f32x4*>(wl + KT * 1024);
+        constexpr int NPAIR = NSLAB / 2;
+#pragma unroll
+        for (int sp = 0; sp < NPAIR; ++sp) {
+            const int s0 = 2 * sp, s1 = 2 * sp + 1;
+            f32x4 acc0 = (s0 == 0 || !kDeriv) ? bias4[g] : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 acc1 = (!kDeriv) ? bias4[g] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const f32x4 w = wf[kt * 64];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc0 = mma_16x16x4<USE_MFMA>(w[r], a[s0][kt][r], acc0);
+                    acc1 = mma_16x16x4<USE_MFMA>(w[r], a[s1][kt][r], acc1);
+                }
+            }
+            f32x4 o0[1] = {acc0}, o1[1] = {acc1};
+            epilogue_tile<1, ACT>(s0, 0, o0, act);
+            epilogue_tile<1, ACT>(s1, 0, o1, act);
+        }
+        if constexpr (NSLAB % 2 == 1) {
+            constexpr int s = NSLAB - 1;
+            f32x4 acc = (s == 0 || !kDeriv) ? bias4[g] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const f32x4 w = wf[kt * 64];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = mma_16x16x4<USE_MFMA>(w[r], a[s][kt][r], acc);
+            }
+            f32x4 o0[1] = {acc};
+            epilogue_tile<1, ACT>(s, 0, o0, act);
+        }
+    }
+#endif
+
     template <int KT, int NT, int ACT = -1>
     AC_DI void layer(const char* wl, int act) {
+#ifdef AC_EXP_LAST2
+        if constexpr (NT == 1 && KT == WT && KT > 1) { layer_last2<KT, ACT>(wl, act); return; }
+#endif
         const f32x4* wf = reinterpret_cast<const f32x4*>(wl) + lane;
         const f32x4* bias4 = reinterpret_cast<const f32x4*>(wl + NT * KT * 1024);
         constexpr int C = NT < CH ? NT : CH;
@@ -412,7 +456,16 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
         const int L = plan.n_layers;
         AC_MARK(st, 1);  // [1] primal aero + input slab
         if (L == 1) {
-            layer<1, 1>(acquire(0), plan.act[0]);
+            // Second-order engines decide the activation of the last (here: only) layer ONCE — a wave-uniform branch around
+            // two straight-line bodies — instead of by a runtime flag inside each slab epilogue: hipcc -O2/-O3 miscompiles
+            // the runtime-flag form of the 21-slab instantiation under some register allocations (the round-1
+            // "unexplained sensitivity": reproduced with tools/exp_last2_lib.sh, correct at -O1 and with this form).
+            if constexpr (SECOND) {
+                const char* wl1 = acquire(0);
+                if (plan.act[0]) layer<1, 1, 1>(wl1, 1); else layer<1, 1, 0>(wl1, 0);
+            } else {
+                layer<1, 1>(acquire(0), plan.act[0]);
+            }
         } else {
             layer_first(acquire(0));
             AC_MARK(st, 2);  // [2] first layer
@@ -423,7 +476,12 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
                 layer<WT, WT, 1>(wl, 1);  // tanh on every layer but the last: ac_set_mlp folds activation-free layers away
                 AC_MARK(st, 4);  // [4] hidden layer GEMM + epilogues
             }
-            layer<WT, 1>(acquire(L - 1), plan.act[L - 1]);
+            if constexpr (SECOND) {  // as for L == 1: no runtime activation flag inside the second-order epilogues
+                const char* wll = acquire(L - 1);
+                if (plan.act[L - 1]) layer<WT, 1, 1>(wll, 1); else layer<WT, 1, 0>(wll, 0);
+            } else {
+                layer<WT, 1>(acquire(L - 1), plan.act[L - 1]);
+            }
             AC_MARK(st, 5);  // [5] last layer
         }
         // outputs: rows 0..5 of tile 0 — row k sits in register k&3 of lane (col, k>>2)
