@@ -270,4 +270,109 @@ __global__ __launch_bounds__(kBlock) void k_step_hess(const DevParams P, const f
     }
 }
 
+// ---- composition across RK4 sub-steps (physical_integration_substeps > 1: dynamics/base.py:463-474, default 10) ----------
+// F = N o S_ns o ... o S_1 with S_s : w_s = (x_{s-1}, u, h = dt / ns) -> x_s.  For phi = lambda . F:
+//   d2 phi / dz2 = sum_s T_s' H_s T_s,   H_s = sum_i mu_{s,i} d2 S_i / dw2 at w_s   (the single-step kernel above),
+//   T_s = d w_s / dz = [ X_{s-1} ; (0 I 0) ; (0 0 1/ns) ],   X_s = d x_s / dz = A_s X_{s-1} + (0 | B_s | c_s / ns),
+//   mu_{s-1} = A_s' mu_s   (mu_ns = lambda; the final normalisation belongs to the last sub-step's kernels).
+// All arrays in the blocked component-major layout of the inputs (UnitAddr), one lane per (unit, column).
+
+// XZn [13][21] = A [13][13] . XZ [13][21] + (0 | B [13][7] | c [13] * inv_ns); XZ == nullptr: X_0 = (I 0 0)
+template <int INST = 0>
+__global__ __launch_bounds__(kBlock) void k_hess_chain(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                       const float* __restrict__ c, const float* __restrict__ XZ,
+                                                       float inv_ns, long n, long blk, float* __restrict__ XZn) {
+    const long unit = (long)blockIdx.x * kBlock + threadIdx.x;
+    const int b = blockIdx.y;  // column of z: 0..20
+    if (unit >= n) return;
+    const UnitAddr ua(unit, blk);
+    const float* Au = A + ua.off(169);
+    float col[13];
+    if (XZ) {
+        const float* Xu = XZ + ua.off(273);
+#pragma unroll
+        for (int k = 0; k < 13; ++k) col[k] = Xu[(long)(k * 21 + b) * blk];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 13; ++k) col[k] = (k == b) ? 1.f : 0.f;
+    }
+    float* out = XZn + ua.off(273);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 13; ++k) s = fmaf(Au[(long)(i * 13 + k) * blk], col[k], s);
+        if (b >= 13 && b < 20) s += Bm[ua.off(91) + (long)(i * 7 + (b - 13)) * blk];
+        if (b == 20) s = fmaf(c[ua.off(13) + (long)i * blk], inv_ns, s);
+        out[(long)(i * 21 + b) * blk] = s;
+    }
+}
+
+// mu_out [13] = A' mu [13]
+template <int INST = 0>
+__global__ __launch_bounds__(kBlock) void k_hess_adjoint(const float* __restrict__ A, const float* __restrict__ mu, long n,
+                                                         long blk, float* __restrict__ mu_out) {
+    const long unit = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (unit >= n) return;
+    const UnitAddr ua(unit, blk);
+    const float* Au = A + ua.off(169);
+    float m[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) m[i] = mu[ua.off(13) + (long)i * blk];
+#pragma unroll
+    for (int j = 0; j < 13; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) s = fmaf(Au[(long)(i * 13 + j) * blk], m[i], s);
+        mu_out[ua.off(13) + (long)j * blk] = s;
+    }
+}
+
+// Hout [21][21] += T' Hs T  with T = [XZ ; (0 I 0) ; (0 0 inv_ns)];  XZ == nullptr: X_0 = (I 0 0).  Lane = (unit, column b).
+template <int INST = 0>
+__global__ __launch_bounds__(kBlock) void k_hess_accum(const float* __restrict__ Hs, const float* __restrict__ XZ,
+                                                       float inv_ns, long n, long blk, float* __restrict__ Hout) {
+    const long unit = (long)blockIdx.x * kBlock + threadIdx.x;
+    const int b = blockIdx.y;
+    if (unit >= n) return;
+    const UnitAddr ua(unit, blk);
+    const float* Hu = Hs + ua.off(441);
+    const float* Xu = XZ ? XZ + ua.off(273) : nullptr;
+    // column b of T
+    float t[21];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) t[k] = Xu ? Xu[(long)(k * 21 + b) * blk] : ((k == b) ? 1.f : 0.f);
+#pragma unroll
+    for (int k = 13; k < 20; ++k) t[k] = (k == b) ? 1.f : 0.f;
+    t[20] = (b == 20) ? inv_ns : 0.f;
+    // m = Hs t
+    float m[21];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) s = fmaf(Hu[(long)(i * 21 + k) * blk], t[k], s);
+        m[i] = s;
+    }
+    // (T' m)_a
+    float* out = Hout + ua.off(441);
+#pragma unroll
+    for (int a = 0; a < 21; ++a) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 13; ++k) s = fmaf(Xu ? Xu[(long)(k * 21 + a) * blk] : ((k == a) ? 1.f : 0.f), m[k], s);
+        if (a >= 13 && a < 20) s += m[a];
+        if (a == 20) s = fmaf(m[20], inv_ns, s);
+        out[(long)(a * 21 + b) * blk] += s;
+    }
+}
+
+// dt_out = dt_in * inv_ns (per-unit step of the sub-steps)
+template <int INST = 0>
+__global__ __launch_bounds__(kBlock) void k_scale_rows(const float* __restrict__ in, float scale, long count,
+                                                       float* __restrict__ out) {
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i < count) out[i] = in[i] * scale;
+}
+
 }  // namespace ac

@@ -76,8 +76,10 @@ struct ac_handle {
     ValuPlan vplan;
     int vwidth;        // 32 or 64
     float* d_vblob;    // weight image [layer][K][N] (+ biases), device
-    float* d_hess_ws;  // [n][4][126] stage tensors of the MLP Hessian path, grown on demand
+    float* d_hess_ws;  // [n][4][126] stage tensors of the MLP Hessian path (ac_reserve_hess_workspace)
     size_t hess_ws_floats;
+    float* d_hess_ws2;  // sub-step composition of the second-order blocks (substeps > 1)
+    size_t hess_ws2_floats;
     float* d_track;  // [nseg][3][4] segment cubics (device)
     TrackDev track;
     // kernels whose dynamic-LDS limit was already raised on this handle's device (hipFuncSetAttribute is not free)
@@ -237,6 +239,7 @@ int ac_destroy(ac_handle* h) {
     if (h->d_vblob) (void)hipFree(h->d_vblob);
     if (h->d_track) (void)hipFree(h->d_track);
     if (h->d_hess_ws) (void)hipFree(h->d_hess_ws);
+    if (h->d_hess_ws2) (void)hipFree(h->d_hess_ws2);
     delete h;
     return AC_OK;
 }
@@ -828,18 +831,10 @@ int ac_quat_rows_f32(ac_handle* h, int mode, const float* X, const float* Xdot, 
 }
 
 // ---- second-order step sensitivities ---------------------------------------------------------------
-static int hess_impl(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, const float* Lam,
-                     long n, long blk, float* Hout, void* stream) {
-    AC_ENTER(h);
-    if (h && n == 0) return AC_OK;
-    if (!h || !X || !U || !Lam || !Hout || n < 0 || blk <= 0) return AC_ERR_BAD_ARG;
-    if (h->dp.p.substeps != 1) return fail(AC_ERR_UNSUPPORTED, "second-order blocks: substeps > 1 not supported");
-    int rc = model_ready(h);
-    if (rc != AC_OK) return rc;
-    hipStream_t st = (hipStream_t)stream;
+// One RK4 sub-step's second-order block with the handle's CURRENT parameters (the caller sets substeps = 1).
+static int hess_single(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, const float* Lam,
+                       long n, long blk, float* Hout, hipStream_t st) {
     int grid = 0;
-    if (h->dp.p.model_kind == AC_MODEL_NN && (size_t)n * kStageFloats > h->hess_ws_floats)
-        return fail(AC_ERR_WORKSPACE, "second-order workspace too small: call ac_reserve_hess_workspace(h, n) first");
     AC_HIP(hipMemsetAsync(Hout, 0, (size_t)n * 441 * sizeof(float), st));
     if (h->dp.p.model_kind == AC_MODEL_NN) {
         // stage tensors (y, J, T at the four RK4 stage points) into the handle's workspace, then the same second-order
@@ -848,7 +843,6 @@ static int hess_impl(ac_handle* h, const float* X, const float* U, float dt, con
         if ((size_t)n * kStageFloats > h->hess_ws_floats)
             return fail(AC_ERR_WORKSPACE, "second-order workspace too small: call ac_reserve_hess_workspace(h, n) first");
         const int grid_t = (int)((n + 63) / 64);
-        const int lds = h->plan.lds_total;
         bool launched = false;
         AC_NN_CASE(2, true, (k_nn_stage_tensors<2, true, 0>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
         AC_NN_CASE(4, true, (k_nn_stage_tensors<4, true, 0>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
@@ -857,11 +851,7 @@ static int hess_impl(ac_handle* h, const float* X, const float* U, float dt, con
         AC_NN_CASE(4, false, (k_nn_stage_tensors<4, false, 0>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
         // width 128 on the matrix cores: the cross pairs between inputs {0, 1} and {3, 4} come from a second launch
         AC_NN_CASE(8, true, (k_nn_stage_tensors<8, true, 1>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
-        if (!launched) {
-            snprintf(g_err, sizeof(g_err), "second-order blocks at width > 64 need the MFMA path (use_mfma = 1)");
-            return AC_ERR_UNSUPPORTED;
-        }
-        (void)lds;
+        if (!launched) return fail(AC_ERR_UNSUPPORTED, "second-order blocks at width > 64 need the MFMA path (use_mfma = 1)");
         AC_HIP(hipGetLastError());
         launch_hess<AC_MODEL_NN>(h, st, X, U, dt, dt_per_unit, Lam, n, blk, Hout, &grid);
         note_launch(h, "k_step_hess", grid, kBlock, 0);
@@ -879,15 +869,102 @@ static int hess_impl(ac_handle* h, const float* X, const float* U, float dt, con
     return AC_OK;
 }
 
+// floats per unit of the sub-step composition workspace (ac_hess.hpp, "composition across RK4 sub-steps")
+static size_t hess_compose_floats(int ns) { return ns > 1 ? (size_t)ns * (13 + 169 + 91 + 13 + 273) + 13 + 13 + 441 + 1 + 13 : 0; }
+
+static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long n, long blk,
+                     float* Xn, float* A, float* Bm, float* c, void* stream);
+
+static int hess_impl(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, const float* Lam,
+                     long n, long blk, float* Hout, void* stream) {
+    AC_ENTER(h);
+    if (h && n == 0) return AC_OK;
+    if (!h || !X || !U || !Lam || !Hout || n < 0 || blk <= 0) return AC_ERR_BAD_ARG;
+    int rc = model_ready(h);
+    if (rc != AC_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (h->dp.p.model_kind == AC_MODEL_NN && (size_t)n * kStageFloats > h->hess_ws_floats)
+        return fail(AC_ERR_WORKSPACE, "second-order workspace too small: call ac_reserve_hess_workspace(h, n) first");
+    const int ns = h->dp.p.substeps;
+    if (ns == 1) return hess_single(h, X, U, dt, dt_per_unit, Lam, n, blk, Hout, st);
+
+    // ---- physical_integration_substeps > 1: compose the per-sub-step blocks (ac_hess.hpp) -------------------------------
+    if ((size_t)n * hess_compose_floats(ns) > h->hess_ws2_floats)
+        return fail(AC_ERR_WORKSPACE, "sub-step composition workspace too small: call ac_reserve_hess_workspace(h, n) first");
+    const size_t N = (size_t)n;
+    float* w = h->d_hess_ws2;
+    float* XS = w;                       w += N * 13 * ns;    // x_0 .. x_{ns-1}   (x_0 is a copy of the caller's X)
+    float* JA = w;                       w += N * 169 * ns;
+    float* JB = w;                       w += N * 91 * ns;
+    float* JC = w;                       w += N * 13 * ns;
+    float* XZ = w;                       w += N * 273 * ns;   // XZ[s] = d x_s / dz for s = 1 .. ns-1 (slot 0 unused)
+    float* MU0 = w;                      w += N * 13;
+    float* MU1 = w;                      w += N * 13;
+    float* HS = w;                       w += N * 441;
+    float* DT = w;                       w += N;
+    float* XN = w;
+    const ac_params saved = h->dp.p;
+    const float inv_ns = 1.0f / (float)ns;
+    const float hdt = dt * inv_ns;
+    const float* hdtp = nullptr;
+    const int g1 = (int)((n + kBlock - 1) / kBlock);
+    if (dt_per_unit) {
+        hipLaunchKernelGGL(k_scale_rows<0>, g1, kBlock, 0, st, dt_per_unit, inv_ns, n, DT);
+        hdtp = DT;
+    }
+    rc = AC_OK;
+    h->dp.p.substeps = 1;
+    // forward: the sub-steps with their first-order blocks, and the chain of state sensitivities
+    for (int s = 0; s < ns && rc == AC_OK; ++s) {
+        const float* xs = s == 0 ? X : XS + N * 13 * s;
+        float* xn = s + 1 < ns ? XS + N * 13 * (s + 1) : XN;
+        h->dp.p.normalise = (s == ns - 1) ? saved.normalise : 0;  // q <- q/|q| once, after the last sub-step
+        rc = sens_impl(h, xs, U, hdt, hdtp, n, blk, xn, JA + N * 169 * s, JB + N * 91 * s, JC + N * 13 * s, stream);
+        if (rc == AC_OK && s + 1 < ns)
+            hipLaunchKernelGGL(k_hess_chain<0>, dim3(g1, 21), kBlock, 0, st, JA + N * 169 * s, JB + N * 91 * s, JC + N * 13 * s,
+                               s == 0 ? (const float*)nullptr : (const float*)(XZ + N * 273 * s), inv_ns, n, blk,
+                               XZ + N * 273 * (s + 1));
+    }
+    // backward: adjoint of the later sub-steps, the block of each sub-step, its congruence into the caller's variables
+    if (rc == AC_OK) rc = hipMemsetAsync(Hout, 0, N * 441 * sizeof(float), st) == hipSuccess ? AC_OK : AC_ERR_HIP;
+    const float* mu = Lam;
+    for (int s = ns - 1; s >= 0 && rc == AC_OK; --s) {
+        const float* xs = s == 0 ? X : XS + N * 13 * s;
+        h->dp.p.normalise = (s == ns - 1) ? saved.normalise : 0;
+        rc = hess_single(h, xs, U, hdt, hdtp, mu, n, blk, HS, st);
+        if (rc != AC_OK) break;
+        hipLaunchKernelGGL(k_hess_accum<0>, dim3(g1, 21), kBlock, 0, st, HS,
+                           s == 0 ? (const float*)nullptr : (const float*)(XZ + N * 273 * s), inv_ns, n, blk, Hout);
+        if (s > 0) {
+            float* mo = (mu == MU0) ? MU1 : MU0;
+            hipLaunchKernelGGL(k_hess_adjoint<0>, g1, kBlock, 0, st, JA + N * 169 * s, mu, n, blk, mo);
+            mu = mo;
+        }
+    }
+    h->dp.p = saved;
+    if (rc != AC_OK) return rc;
+    note_launch(h, "k_step_hess (composed over sub-steps)", g1, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
 int ac_reserve_hess_workspace(ac_handle* h, long n) {
     AC_ENTER(h);
     if (!h || n < 0) return AC_ERR_BAD_ARG;
     const size_t need = (size_t)n * kStageFloats;
-    if (need <= h->hess_ws_floats) return AC_OK;
-    if (h->d_hess_ws) (void)hipFree(h->d_hess_ws);
-    h->d_hess_ws = nullptr; h->hess_ws_floats = 0;
-    AC_HIP(hipMalloc((void**)&h->d_hess_ws, need * sizeof(float)));
-    h->hess_ws_floats = need;
+    if (need > h->hess_ws_floats) {
+        if (h->d_hess_ws) (void)hipFree(h->d_hess_ws);
+        h->d_hess_ws = nullptr; h->hess_ws_floats = 0;
+        AC_HIP(hipMalloc((void**)&h->d_hess_ws, need * sizeof(float)));
+        h->hess_ws_floats = need;
+    }
+    const size_t need2 = (size_t)n * hess_compose_floats(h->dp.p.substeps);  // sized for the handle's CURRENT sub-step count
+    if (need2 > h->hess_ws2_floats) {
+        if (h->d_hess_ws2) (void)hipFree(h->d_hess_ws2);
+        h->d_hess_ws2 = nullptr; h->hess_ws2_floats = 0;
+        AC_HIP(hipMalloc((void**)&h->d_hess_ws2, need2 * sizeof(float)));
+        h->hess_ws2_floats = need2;
+    }
     return AC_OK;
 }
 

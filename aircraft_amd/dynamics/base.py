@@ -314,7 +314,7 @@ class SixDOF(ABC):
     def step_hess(self, x, u, dt, lam, out=None):
         """Hessian of lam . F(x, u, dt) over z = (x[13], u[7], dt): (21, 21, n) — the block the defect rows contribute to
         the Lagrangian Hessian IPOPT evaluates as `nlp_hess_l` (control/base.py:279-280; todo.md:102).
-        lam (13, n): multipliers of the rows of F.  One RK4 sub-step only."""
+        lam (13, n): multipliers of the rows of F.  Any number of RK4 sub-steps (composed per sub-step on the device)."""
         lib = self._sync()
         torch = _torch()
         X, npx, vec = self._in(x, self.num_states, "x")
@@ -337,11 +337,16 @@ class SixDOF(ABC):
         """Size the handle's second-order workspace for n units.  Host-side and idempotent (the library only grows
         it); the compute calls themselves never allocate, so call this before capturing a hipGraph."""
         n = int(n)
+        ns = int(self.physical_integration_substeps or 1)
+        if ns != getattr(self, "_hess_reserved_substeps", ns):
+            self._hess_reserved = 0  # the composition buffers are sized for the sub-step count
+        self._hess_reserved_substeps = ns
         if n > getattr(self, "_hess_reserved", 0):
             torch = _torch()
             if torch.cuda.is_current_stream_capturing():
                 raise _lib.AircraftHipError("second-order workspace must be reserved before stream capture: "
                                             "call system._reserve_hess(n) (ac_reserve_hess_workspace) first")
+            self._sync()  # push the current sub-step count first: the reservation is sized for it
             _lib.check(_lib.load().ac_reserve_hess_workspace(self._handle, n), "ac_reserve_hess_workspace")
             self._hess_reserved = n
 

@@ -168,15 +168,19 @@ int ac_quat_rows_f32(ac_handle* h, int mode, const float* X, const float* Xdot, 
  * host-side call that may allocate — BEFORE the first compute call (and before capturing a hipGraph); the compute calls
  * themselves never allocate, free or synchronise and return AC_ERR_WORKSPACE when the workspace is too small.  The
  * workspace is one buffer per handle: second-order calls of one handle must be ordered on one stream (or use one handle
- * per stream).  substeps == 1 only,
- * AC_ERR_UNSUPPORTED otherwise (also for an MLP wider than 64 with use_mfma = 0: the VALU validation flavour has no
- * second-order instance at that width).  Hout is zero-filled by the call (hipMemsetAsync on `stream`) before the active block is
+ * per stream).  physical_integration_substeps > 1 (the reference's default is 10, dynamics/base.py:12, 463-474) composes the
+ * per-sub-step blocks: d2/dz2 = sum_s T_s' H_s T_s with T_s = d(x_{s-1}, u, dt/ns)/dz carried by the first-order chain and the
+ * multipliers pulled back through the later sub-steps (mu_{s-1} = A_s' mu_s); it needs (559 ns + 481) n floats more of the
+ * same reserved workspace, sized for the handle's sub-step count at the time of ac_reserve_hess_workspace.
+ * AC_ERR_UNSUPPORTED for an MLP wider than 64 with use_mfma = 0 (the cross-lane validation flavour has no second-order
+ * instance at that width).  Hout is zero-filled by the call (hipMemsetAsync on `stream`) before the active block is
  * written.  ac_shoot_hess_f32 reads rollout-shaped X [H(+1)][13][B], U [H][7][B], lambda [H][13][B] in place and writes
  * Hout [H][21][21][B]. */
 int ac_step_hess_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit,
                      const float* lambda, long n, float* Hout, void* stream);
-/* Size the MLP path's workspace for n units (hipFree + hipMalloc when it must grow: implicit device synchronisation, not
- * capturable); a no-op for the other models and when it is already large enough. */
+/* Size the second-order workspaces for n units: the MLP path's stage tensors and, when the handle integrates with more
+ * than one RK4 sub-step, the composition buffers (hipFree + hipMalloc when one must grow: implicit device synchronisation,
+ * not capturable); a no-op when both are already large enough.  Call again after changing `substeps`. */
 int ac_reserve_hess_workspace(ac_handle* h, long n);
 int ac_shoot_hess_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit,
                       const float* lambda, long B, long H, float* Hout, void* stream);

@@ -120,14 +120,33 @@ def test_shooting_hessian_in_place_equals_flat_call(gpu):
     assert torch.equal(Hs.permute(1, 2, 0, 3).reshape(21, 21, H * B), Hf)
 
 
-def test_hessian_unsupported_cases_fail_loudly(gpu):
-    from aircraft_amd import AircraftHipError
+def test_hessian_workspace_must_be_reserved_through_the_abi(gpu):
+    """The compute entry points never allocate: a raw ABI call without ac_reserve_hess_workspace returns AC_ERR_WORKSPACE
+    (MLP stage tensors; sub-step composition buffers), with a message, and works after the reservation — also when the
+    sub-step count changes afterwards (the Python layer re-reserves)."""
+    import ctypes as C
 
+    import torch
+
+    from aircraft_amd import _lib
+
+    lib = _lib.load()
     X, U, lam = units(8, seed=1)
+    Xd, Ud, Ld = dev(X, gpu), dev(U, gpu), dev(lam, gpu)
+    out = torch.empty((21, 21, 8), device=gpu)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    for ac in (make_aircraft("nn", hidden=(32, 32)), make_aircraft("poly", substeps=2)):
+        ac._sync()
+        st = ac._stream()
+        assert lib.ac_step_hess_f32(ac._handle, p(Xd), p(Ud), C.c_float(0.01), None, p(Ld), 8, p(out), st) == -6
+        assert b"ac_reserve_hess_workspace" in lib.ac_last_error()
+        assert lib.ac_reserve_hess_workspace(ac._handle, 8) == 0
+        assert lib.ac_step_hess_f32(ac._handle, p(Xd), p(Ud), C.c_float(0.01), None, p(Ld), 8, p(out), st) == 0
     ac = make_aircraft("poly")
-    ac.physical_integration_substeps = 2
-    with pytest.raises(AircraftHipError, match="UNSUPPORTED"):
-        ac.step_hess(dev(X, gpu), dev(U, gpu), 0.01, dev(lam, gpu))
+    a = ac.step_hess(Xd, Ud, 0.01, Ld).clone()
+    ac.physical_integration_substeps = 2  # attribute change after the first reservation: picked up, re-reserved
+    b = ac.step_hess(Xd, Ud, 0.01, Ld)
+    assert torch.isfinite(b).all() and not torch.equal(a, b)
 
 
 def test_wide_valu_flavour_is_refused(gpu):
@@ -227,3 +246,40 @@ def test_hessian_reads_nothing_it_did_not_write(gpu, hidden):
     torch.cuda.synchronize()
     assert torch.isfinite(got).all()
     assert torch.equal(got, clean)
+
+
+@pytest.mark.parametrize("model,hidden,substeps,normalise", [("default", None, 3, True), ("poly", None, 10, False),
+                                                             ("poly", None, 10, True), ("nn", (64, 64, 64), 4, True),
+                                                             ("nn", None, 10, True)])
+def test_hessian_composed_over_substeps(gpu, model, hidden, substeps, normalise):
+    """physical_integration_substeps > 1 (the reference's default is 10): the blocks of the sub-steps composed on the
+    device — sum_s T_s' H_s T_s with the first-order chain and the pulled-back multipliers — against central differences
+    of the oracle's exact Jacobians of the WHOLE sub-stepped update."""
+    ac = make_aircraft(model, hidden=hidden, substeps=substeps, normalise=normalise)
+    orc = make_oracle(ac)
+    n = 70
+    X, U, lam = units(n, seed=77)
+    dt = 0.02
+    Hm = ac.step_hess(dev(X, gpu), dev(U, gpu), dt, dev(lam, gpu)).cpu().numpy().astype(np.float64)
+    want = oracle_step_hessian(orc, X, U, dt, lam)
+    assert Hm.shape == (21, 21, n) and np.isfinite(Hm).all()
+    from tests.helpers import parity_report
+    parity_report(f"hess_substeps[{model}-{hidden}-{substeps}]", rel_block=rel_block(Hm, want))
+    assert rel_block(Hm, want) < 1e-3
+    assert np.abs(Hm - Hm.transpose(1, 0, 2)).max() <= 2e-5 * np.abs(Hm).max()
+    for z in (0, 1, 2, 16, 17, 18):
+        assert not Hm[z].any() and not Hm[:, z].any()
+    # per-unit dt and the in-place shooting layout go through the same composition
+    from aircraft_amd.control import MultipleShooting
+    import torch
+    dts = f32_exact(np.random.default_rng(5).uniform(0.01, 0.03, n))
+    H2 = ac.step_hess(dev(X, gpu), dev(U, gpu), dev(dts, gpu), dev(lam, gpu)).cpu().numpy().astype(np.float64)
+    assert rel_block(H2[:, :, :24], oracle_step_hessian(orc, X[:, :24], U[:, :24], dts[:24], lam[:, :24])) < 1e-3
+    ms = MultipleShooting(system=ac, dt=dt, num_nodes=7, opts={"quaternion": "integration" if normalise else None})
+    B = n // 7
+    Xs = dev(X[:, : 7 * B].reshape(13, 7, B).transpose(1, 0, 2), gpu)
+    Us = dev(U[:, : 7 * B].reshape(7, 7, B).transpose(1, 0, 2), gpu)
+    Ls = dev(lam[:, : 7 * B].reshape(13, 7, B).transpose(1, 0, 2), gpu)
+    Hs = ms.hessian(Xs, Us, Ls)
+    flat = ac.step_hess(dev(X[:, : 7 * B], gpu), dev(U[:, : 7 * B], gpu), dt, dev(lam[:, : 7 * B], gpu))
+    assert torch.allclose(Hs.permute(1, 2, 0, 3).reshape(21, 21, 7 * B), flat, rtol=0, atol=0)
