@@ -27,7 +27,7 @@ struct ValuPlan {
     int n_layers;                 // >= 2 (after the fold); layer 0: 8 (5 padded) -> W, hidden: W -> W, last: W -> 8 (6 padded)
     int act_last;                 // tanh on the last layer?
     int w_off[AC_MAX_LAYERS];     // float offset of the layer's weights in the image: [K][N] row-major (k-major) for all
-                                  // layers but the last, which is stored transposed [8][K]
+                                  // layers but the last, which is stored transposed [8][K + 4] (padded rows)
     int b_off[AC_MAX_LAYERS];     // float offset of the bias (N floats, zero padded)
     int image_floats;             // padded to a multiple of 256 (whole 1-KiB LDS-DMA pieces)
 };
@@ -91,10 +91,11 @@ template <int WIDTH> struct MlpEngineTiled {
         __builtin_amdgcn_wave_barrier();
     }
 
-    // One 4-deep k-step:  acc[12 rows][NP neuron pairs] += A[rows][k0 .. k0+3] * W[k0 .. k0+3][NB tj .. NB tj + NB - 1].
-    // The weight fragment of a step is requested one step AHEAD (two register banks, the k loop unrolled by two), so only
-    // the activation rows are fetched in the step itself — and those are consumed one after the other, row r + 1 .. 11
-    // still in flight while row r computes (the LDS returns in issue order).
+    // One 4-deep k-step:  acc[12 rows][NP neuron pairs] += A[rows][k0 .. k0+3] * W[k0 .. k0+3][NB tj .. NB tj + NB - 1],
+    // run as two HALF steps of six rows (one unit's six slabs each).  Everything a half step consumes was requested one
+    // half step (96 packed FMAs) earlier: while unit 0's rows compute, unit 1's rows and the next step's weight fragment
+    // are in flight; while unit 1's rows compute, the next step's unit-0 rows are (PMC on the first version, which fetched
+    // a step's rows inside the step: SQ_WAIT_ANY = 24 % of the wave's cycles).  Two weight banks, the k loop unrolled by two.
     template <int N> AC_DI void load_w(f32x4 (&wv)[4][NQ], const float* __restrict__ w, int k0) const {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
@@ -102,27 +103,47 @@ template <int WIDTH> struct MlpEngineTiled {
             for (int h = 0; h < NQ; ++h)
                 wv[kk][h] = *reinterpret_cast<const f32x4*>(w + (k0 + kk) * N + NB * tj + 4 * h);
     }
-    AC_DI void kstep(f32x2 (&acc)[12][NP], const f32x4 (&wv)[4][NQ], int k0) const {
-        f32x4 a[12];
+    AC_DI void load_a(f32x4 (&a)[6], int u, int k0) const {
 #pragma unroll
-        for (int r = 0; r < 12; ++r)
-            a[r] = *reinterpret_cast<const f32x4*>(act + row_of(r / 6, r % 6) * S + k0);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < 6; ++s) a[s] = *reinterpret_cast<const f32x4*>(act + row_of(u, s) * S + k0);
+    }
+    AC_DI void half_step(f32x2 (&acc)[12][NP], int u, const f32x4 (&a)[6], const f32x4 (&wv)[4][NQ]) const {
 #pragma unroll
-        for (int r = 0; r < 12; ++r) {
-            const f32x2 a01 = {a[r][0], a[r][1]}, a23 = {a[r][2], a[r][3]};
+        for (int s = 0; s < 6; ++s) {
+            const f32x2 a01 = {a[s][0], a[s][1]}, a23 = {a[s][2], a[s][3]};
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     const f32x2 wp = {wv[kk][p >> 1][2 * (p & 1)], wv[kk][p >> 1][2 * (p & 1) + 1]};
-                    if (kk == 0) pk_fma_alo(acc[r][p], a01, wp);
-                    else if (kk == 1) pk_fma_ahi(acc[r][p], a01, wp);
-                    else if (kk == 2) pk_fma_alo(acc[r][p], a23, wp);
-                    else pk_fma_ahi(acc[r][p], a23, wp);
+                    if (kk == 0) pk_fma_alo(acc[6 * u + s][p], a01, wp);
+                    else if (kk == 1) pk_fma_ahi(acc[6 * u + s][p], a01, wp);
+                    else if (kk == 2) pk_fma_alo(acc[6 * u + s][p], a23, wp);
+                    else pk_fma_ahi(acc[6 * u + s][p], a23, wp);
                 }
             }
         }
+    }
+    // steps k0 and k0 + 4 with the weights of k0 in wA on entry (and of k0 + 8 on exit), unit-0 rows of k0 in a0 on entry
+    // (and of k0 + 8 on exit); `more`: further steps follow
+    template <int N> AC_DI void two_steps(f32x2 (&acc)[12][NP], const float* __restrict__ w, int k0, int knext, f32x4 (&a0)[6],
+                                          f32x4 (&wA)[4][NQ]) const {
+        f32x4 a1[6], wB[4][NQ];
+        load_a(a1, 1, k0); load_w<N>(wB, w, k0 + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        half_step(acc, 0, a0, wA);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(a0, 0, k0 + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        half_step(acc, 1, a1, wA);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(a1, 1, k0 + 4); load_w<N>(wA, w, knext);
+        __builtin_amdgcn_sched_barrier(0);
+        half_step(acc, 0, a0, wB);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(a0, 0, knext);
+        __builtin_amdgcn_sched_barrier(0);
+        half_step(acc, 1, a1, wB);
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -172,22 +193,19 @@ template <int WIDTH> struct MlpEngineTiled {
 #pragma unroll
             for (int p = 0; p < NP; ++p) acc[r][p] = f32x2{0.f, 0.f};
         const float* w = wimg + plan.w_off[l];
-        f32x4 wA[4][NQ], wB[4][NQ];
+        f32x4 wA[4][NQ], a0[6];
         load_w<WIDTH>(wA, w, 0);
+        load_a(a0, 0, 0);
 #pragma nounroll
-        for (int k0 = 0; k0 < K; k0 += 8) {
-            load_w<WIDTH>(wB, w, k0 + 4);
-            kstep(acc, wA, k0);
-            load_w<WIDTH>(wA, w, k0 + 8 < K ? k0 + 8 : 0);  // (the last request is a harmless re-read of step 0)
-            kstep(acc, wB, k0 + 4);
-        }
+        for (int k0 = 0; k0 < K; k0 += 8)
+            two_steps<WIDTH>(acc, w, k0, k0 + 8 < K ? k0 + 8 : 0, a0, wA);  // (the last prefetch is a harmless re-read of step 0)
         epilogue_store<true>(acc, wimg + plan.b_off[l]);  // tanh on every layer but the last (ac_set_mlp folds the others)
     }
 
     // Last layer, WIDTH -> 6 (padded 8): lane (i, j) computes output neuron j of its 12 rows; the packed FMA runs over
     // k-pairs (even / odd partial sums) against the transposed weights Wt[j][k].
     AC_DI void last_layer(int l) {
-        const float* wt = wimg + plan.w_off[l] + tj * WIDTH;
+        const float* wt = wimg + plan.w_off[l] + tj * (WIDTH + 4);  // rows padded by 4: the eight lane columns read eight distinct bank groups
         f32x2 acc[12];
 #pragma unroll
         for (int r = 0; r < 12; ++r) acc[r] = f32x2{0.f, 0.f};

@@ -408,7 +408,7 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
         for (int l = 0; l < n_layers; ++l) {
             const bool last = l == n_layers - 1;
             const int K = l == 0 ? 8 : vw, N = last ? 8 : vw;
-            vp.w_off[l] = (int)off; off += (size_t)K * N;
+            vp.w_off[l] = (int)off; off += last ? (size_t)N * (K + 4) : (size_t)K * N;  // last layer: transposed, rows padded
             vp.b_off[l] = (int)off; off += (size_t)N;
         }
         vp.image_floats = (int)((off + 255) / 256 * 256);
@@ -420,7 +420,7 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
             for (int k = 0; k < nin; ++k)
                 for (int nn = 0; nn < nout; ++nn) {
                     const float wv = fW[(size_t)l][(size_t)nn * nin + k];
-                    if (last) wd[(size_t)nn * K + k] = wv;   // Wt[j][k]
+                    if (last) wd[(size_t)nn * (K + 4) + k] = wv;   // Wt[j][k], row stride K + 4
                     else wd[(size_t)k * N + nn] = wv;        // W[k][n]
                 }
             for (int nn = 0; nn < nout; ++nn) vimg[(size_t)vp.b_off[l] + nn] = fb[(size_t)l][(size_t)nn];

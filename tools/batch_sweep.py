@@ -3,7 +3,7 @@
 Shows the round quantisation (one 64-unit workgroup per CU is resident) and the asymptote."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for B in (256, 983, 1024, 2048, 4096, 4915, 8192, 16384, 65536):
+for B in (256, 512, 983, 1024, 2048, 4096, 4915, 8192, 16384, 65536):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(B), "--steps", "20", "--warmup", "3",
                           "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True).stdout.strip().splitlines()[-1]
     d = json.loads(out)
