@@ -209,18 +209,39 @@ template <int WIDTH> struct MlpEngineTiled {
         f32x2 acc[12];
 #pragma unroll
         for (int r = 0; r < 12; ++r) acc[r] = f32x2{0.f, 0.f};
-#pragma nounroll
-        for (int k0 = 0; k0 < WIDTH; k0 += 8) {
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + k0), w1 = *reinterpret_cast<const f32x4*>(wt + k0 + 4);
+        // 8-deep k-steps, software-pipelined like the dense layers: the 24 row reads and 2 weight reads of step k0 + 8 are in
+        // flight while step k0 computes (stamps of the first version: this layer took 16 % of the wave for 5 % of the FMAs)
+        f32x4 ra[2][12][2], rw[2][2];
+        auto fetch = [&](int b, int k0) {
+            rw[b][0] = *reinterpret_cast<const f32x4*>(wt + k0);
+            rw[b][1] = *reinterpret_cast<const f32x4*>(wt + k0 + 4);
 #pragma unroll
             for (int r = 0; r < 12; ++r) {
                 const float* ar = act + row_of(r / 6, r % 6) * S + k0;
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar), a1 = *reinterpret_cast<const f32x4*>(ar + 4);
-                pk_fma_pair(acc[r], f32x2{a0[0], a0[1]}, f32x2{w0[0], w0[1]});
-                pk_fma_pair(acc[r], f32x2{a0[2], a0[3]}, f32x2{w0[2], w0[3]});
-                pk_fma_pair(acc[r], f32x2{a1[0], a1[1]}, f32x2{w1[0], w1[1]});
-                pk_fma_pair(acc[r], f32x2{a1[2], a1[3]}, f32x2{w1[2], w1[3]});
+                ra[b][r][0] = *reinterpret_cast<const f32x4*>(ar);
+                ra[b][r][1] = *reinterpret_cast<const f32x4*>(ar + 4);
             }
+        };
+        auto compute = [&](int b) {
+#pragma unroll
+            for (int r = 0; r < 12; ++r) {
+                pk_fma_pair(acc[r], f32x2{ra[b][r][0][0], ra[b][r][0][1]}, f32x2{rw[b][0][0], rw[b][0][1]});
+                pk_fma_pair(acc[r], f32x2{ra[b][r][0][2], ra[b][r][0][3]}, f32x2{rw[b][0][2], rw[b][0][3]});
+                pk_fma_pair(acc[r], f32x2{ra[b][r][1][0], ra[b][r][1][1]}, f32x2{rw[b][1][0], rw[b][1][1]});
+                pk_fma_pair(acc[r], f32x2{ra[b][r][1][2], ra[b][r][1][3]}, f32x2{rw[b][1][2], rw[b][1][3]});
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int k0 = 0; k0 < WIDTH; k0 += 16) {
+            fetch(1, k0 + 8);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(0, k0 + 16 < WIDTH ? k0 + 16 : 0);  // (the last prefetch is a harmless re-read of step 0)
+            __builtin_amdgcn_sched_barrier(0);
+            compute(1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         const float bj = wimg[plan.b_off[l] + tj];
         float o[12];
@@ -267,6 +288,7 @@ template <int WIDTH> struct MlpEngineTiled {
             }
         }
         wave_sync();
+        AC_MARK(st, 3);  // [3] operand rows of layer 0 written
         dense_layer<8>(0);
         AC_MARK(st, 2);
 #pragma nounroll
@@ -299,7 +321,13 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_step_sens_tiled(const DevParam
                                                                   float* __restrict__ Bm, float* __restrict__ c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MlpEngineTiled<WIDTH> eng(plan, blob, smem);
+    eng.st.start();
     eng.load_weights();
+    AC_MARK(eng.st, 0);  // [0] prologue: weight image into LDS
+#ifdef AC_STAMPS
+    unsigned long long* stamp_buf = reinterpret_cast<unsigned long long*>(c);  // the diagnostic flavor's stamp buffer travels in `c`
+    c = nullptr;
+#endif
     const WaveUnit w(n, blk);
     float xv[13], uv[7];
     load_rows<13>(X, w.ua, xv);
@@ -308,6 +336,10 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_step_sens_tiled(const DevParam
     Dual<4> x[13];
     MlpCoeffs<MlpEngineTiled<WIDTH>> coeffs(eng);
     sens_update<4>(P, coeffs, w.g, w.col, w.ua, xv, uv, hv, x, A, Bm, c, w.live);
+    AC_MARK(eng.st, 7);  // [7] dual rigid body + RK4 combine after the last network evaluation
+#ifdef AC_STAMPS
+    eng.st.flush(stamp_buf);
+#endif
     if (w.live) {
         const UnitAddr uo = w.ua.late();
         if (w.g == 0) {
