@@ -464,6 +464,25 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
 static int launch_nn_fwd(ac_handle* h, int op, const float* X, const float* U, float dt, const float* dtp, long n,
                          long blk, float* out, hipStream_t st) {
     bool launched = false;
+    if (!h->use_mfma && h->has_vplan) {
+        // "MFMA off": the value-only tile of ac_mlp_valu.hpp, 64 units per wave, 256 per workgroup
+        const int grid = (int)((n + kBlock - 1) / kBlock);
+        const int lds = h->vplan.image_floats * 4 + 4 * 64 * (h->vwidth + 4) * 4;
+#define AC_TILED_FWD(W_, OP_)                                                                                      \
+        if (h->vwidth == W_ && op == OP_) {                                                                        \
+            auto kern = k_nn_fwd_tiled<W_, OP_>;                                                                   \
+            int rc_ = set_lds_limit(h, kern, lds);                                                                 \
+            if (rc_ != AC_OK) return rc_;                                                                          \
+            hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->vplan, h->d_vblob, X, U, dt, dtp, n, blk, out); \
+        }
+        AC_TILED_FWD(32, OP_DERIV) AC_TILED_FWD(32, OP_STEP) AC_TILED_FWD(32, OP_AERO)
+        AC_TILED_FWD(64, OP_DERIV) AC_TILED_FWD(64, OP_STEP) AC_TILED_FWD(64, OP_AERO)
+#undef AC_TILED_FWD
+        note_launch(h, op == OP_DERIV ? "k_nn_fwd_tiled<deriv>" : (op == OP_STEP ? "k_nn_fwd_tiled<step>" : "k_nn_fwd_tiled<aero>"), grid,
+                    kBlock, lds);
+        AC_HIP(hipGetLastError());
+        return AC_OK;
+    }
     // Two kernels: k_nn_fwd (16 units per wave, 64 per workgroup) and k_nn_fwd4 (four value slabs per wave, 256 units per
     // workgroup: the per-layer fixed costs are shared, measured 3.4x the time of a 64-unit workgroup for 4x the units).
     // One workgroup per CU is resident, so time goes in whole ROUNDS over the CUs and the last, partly filled round costs
@@ -585,6 +604,22 @@ int ac_rollout_f32(ac_handle* h, const float* X0, const float* U, float dt, long
     if (rc != AC_OK) return rc;
     if (B == 0) return AC_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (h->dp.p.model_kind == AC_MODEL_NN && !h->use_mfma && h->has_vplan) {
+        const int grid = (int)((B + kBlock - 1) / kBlock);
+        const int lds = h->vplan.image_floats * 4 + 4 * 64 * (h->vwidth + 4) * 4;
+#define AC_TILED_ROLL(W_)                                                                                          \
+        if (h->vwidth == W_) {                                                                                     \
+            auto kern = k_nn_rollout_tiled<W_>;                                                                    \
+            int rc_ = set_lds_limit(h, kern, lds);                                                                 \
+            if (rc_ != AC_OK) return rc_;                                                                          \
+            hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->vplan, h->d_vblob, X0, U, dt, B, H, Xout);   \
+        }
+        AC_TILED_ROLL(32) AC_TILED_ROLL(64)
+#undef AC_TILED_ROLL
+        note_launch(h, "k_nn_rollout_tiled", grid, kBlock, lds);
+        AC_HIP(hipGetLastError());
+        return AC_OK;
+    }
     if (h->dp.p.model_kind == AC_MODEL_NN) {
         const long groups = (B + 15) / 16;  // 16 instances per wave-slab
         bool launched = false;

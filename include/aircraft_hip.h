@@ -90,8 +90,11 @@ int ac_set_params(ac_handle* h, const ac_params* params);
  *                                                                                 (coefficient_models.py:106-133)
  * mlp:    n_layers Linear layers; W[l] is [widths[l+1]][widths[l]] row-major (torch layout); act[l] = 0 identity,
  *         1 tanh after layer l; widths[0] must be 5, widths[n_layers] must be 6; input/output scalers as in
- *         ScaledModel (surrogates/models.py:101-155).  use_mfma = 0 selects the VALU cross-lane matmul
- *         ("MFMA off" validation baseline), 1 the v_mfma_f32_16x16x4_f32 path.
+ *         ScaledModel (surrogates/models.py:101-155).  use_mfma = 1: the v_mfma_f32_16x16x4_f32 engines.  use_mfma = 0
+ *         ("MFMA off", BASELINE configs[1]): the register-tiled v_pk_fma_f32 engine on the vector ALUs for hidden widths
+ *         <= 64 and at least two layers after the fold (step, derivative, getters, rollout, step + sensitivities, df/dx);
+ *         wider nets, single-layer nets, the second-order path and the policy rollout of this flavour use the cross-lane
+ *         validation form or are refused (see the entry points).
  *         An activation-free layer that is not the last is folded into its successor on the host, in float64
  *         (W2 (W1 x + b1) + b2 = (W2 W1) x + W2 b1 + b2): the reference checkpoint's Linear-Linear-Tanh-Linear net
  *         (surrogates/models.py:114-123) runs as 5-32-6.  Same function, fewer layers; results differ from a
