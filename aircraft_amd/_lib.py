@@ -43,6 +43,11 @@ class IlqrCost(C.Structure):
                 ("x_goal", C.c_float * 13), ("u_min", C.c_float * 7), ("u_max", C.c_float * 7), ("reg", C.c_float)]
 
 
+class EnvelopePenalty(C.Structure):
+    """struct ac_envelope_penalty (include/aircraft_hip.h)."""
+    _fields_ = [("lo", C.c_float * 4), ("hi", C.c_float * 4), ("weight", C.c_float)]
+
+
 class MhttWeights(C.Structure):
     """struct ac_mhtt_weights (include/aircraft_hip.h); defaults are moving_horizon.py:47-55."""
     _fields_ = [("w_tracking", C.c_float), ("w_progress", C.c_float), ("w_progress_rate", C.c_float),
@@ -71,6 +76,8 @@ PROTOTYPES = {
     "ac_shoot_derivative_sens_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP]),
     "ac_envelope_f32": (C.c_int, [_VP, _VP, C.c_long, _VP, _VP, _VP]),
     "ac_shoot_envelope_f32": (C.c_int, [_VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP]),
+    "ac_envelope_cost_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
+    "ac_envelope_model_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP]),
     "ac_quat_rows_f32": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP]),
     "ac_step_hess_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _VP, C.c_long, _VP, _VP]),
     "ac_reserve_hess_workspace": (C.c_int, [_VP, C.c_long]),

@@ -64,14 +64,22 @@ class QuadraticCost:
 
 class ILQR(MultipleShooting):
     def __init__(self, *, system, dt: float = 0.01, num_nodes: int, cost: QuadraticCost, opts: Optional[dict] = None,
-                 alphas: Sequence[float] = (1.0, 0.5, 0.25, 0.1, 0.03), hessian: str = "gauss-newton"):
+                 alphas: Sequence[float] = (1.0, 0.5, 0.25, 0.1, 0.03), hessian: str = "gauss-newton",
+                 envelope_weight: float = 0.0, envelope_bounds=None):
         """hessian: 'gauss-newton' (first-order dynamics in the backward pass: iLQR) or 'exact' (adds the second-order
-        terms  sum_i lambda_i d2F_i/dz dz  of every node — what IPOPT gets from `nlp_hess_l`)."""
+        terms  sum_i lambda_i d2F_i/dz dz  of every node — what IPOPT gets from `nlp_hess_l`).
+        envelope_weight > 0: the flight envelope of AircraftControl.state_constraint (control/aircraft.py:44-59:
+        20^2 <= |v_rel|^2 <= 100^2, |beta| <= 10 deg, |alpha| <= 20 deg, z < 0) as a soft constraint — the squared violation
+        of its four rows, times the weight, at every node, with its Gauss-Newton model in the backward pass (IPOPT
+        enforces the rows as hard constraints; the control box stays a hard clip).  envelope_bounds: ((lo, hi),) * 4,
+        default `system.ENVELOPE_BOUNDS`."""
         super().__init__(system=system, dt=dt, num_nodes=num_nodes, opts=opts or {"quaternion": "integration"})
         assert 1 <= len(alphas) <= 8 and hessian in ("gauss-newton", "exact")
         self.cost = cost
         self.alphas = [float(a) for a in alphas]
         self.hessian_mode = hessian
+        self.envelope_weight = float(envelope_weight)
+        self.envelope_bounds = envelope_bounds
         self._ws = None
 
     # ---- device workspace (allocated once per (B, H)) ------------------------------------------------
@@ -87,7 +95,46 @@ class ILQR(MultipleShooting):
                 self._ws.update(Lam=f(H, 13, B), Hz=f(H, 21, 21, B))
                 self.system._sync()
                 self.system._reserve_hess(H * B)  # host-side, once: the solve itself stays allocation-free (capturable)
+            if self.envelope_weight > 0:
+                # constant-cost rows as per-node arrays (the penalty gradient is added to glin every iteration)
+                c = self.cost
+                nq = torch.tensor([list(c.q)] * H + [list(c.qf)], device=dev, dtype=torch.float32)        # (H+1, 13)
+                nx = torch.tensor([list(c.x_ref)] * H + [list(c.x_goal)], device=dev, dtype=torch.float32)
+                self._ws.update(env_q=nq[:, :, None].expand(H + 1, 13, B).contiguous(),
+                                env_xref=nx[:, :, None].expand(H + 1, 13, B).contiguous(), env_glin=f(H + 1, 13, B))
+                if "Hz" not in self._ws:
+                    self._ws["Hz"] = f(H, 21, 21, B)
         return self._ws
+
+    def _envelope_struct(self):
+        b = self.envelope_bounds or self.system.ENVELOPE_BOUNDS
+        big = 3.0e38
+        clamp = lambda v: max(-big, min(big, float(v)))  # noqa: E731  (inf does not survive some float paths: use +-FLT_MAX)
+        p = _lib.EnvelopePenalty()
+        p.lo[:] = [clamp(r[0]) for r in b]
+        p.hi[:] = [clamp(r[1]) for r in b]
+        p.weight = self.envelope_weight
+        return p
+
+    def envelope_cost(self, X, cost_inout):
+        """cost_inout[b] += envelope_weight * sum_k sum_r violation_r(x_k)^2 (in place, on the device)."""
+        lib = self.system._sync()
+        H, B = X.shape[0] - 1, X.shape[2]
+        p = self._envelope_struct()
+        _lib.check(lib.ac_envelope_cost_f32(self.system._handle, C.byref(p), X.data_ptr(), B, H, cost_inout.data_ptr(),
+                                            self.system._stream()), "ac_envelope_cost_f32")
+        return cost_inout
+
+    def _envelope_model(self, X, glin=None, Hz=None):
+        """Adds the penalty's gradient to glin (N+1, 13, B) and / or its Gauss-Newton curvature to the (x, x) block of
+        Hz (N, 21, 21, B), in place."""
+        lib = self.system._sync()
+        H, B = X.shape[0] - 1, X.shape[2]
+        p = self._envelope_struct()
+        _lib.check(lib.ac_envelope_model_f32(self.system._handle, C.byref(p), X.data_ptr(), B, H,
+                                             glin.data_ptr() if glin is not None else None,
+                                             Hz.data_ptr() if Hz is not None else None, self.system._stream()),
+                   "ac_envelope_model_f32")
 
     def _cstruct(self):
         return C.byref(self.cost.struct())
@@ -167,15 +214,28 @@ class ILQR(MultipleShooting):
         ws = self._workspace(B, U.device)
         na = len(self.alphas)
         self.linearise(X, U, want_c=False, out=(ws["F"], ws["A"], ws["Bm"], None))
-        node = self._node_cost(X, U)
+        node = self._node_cost(X, U)  # None, or a subclass's per-node arrays (rewritten by it every iteration)
         Hz = None
+        env = self.envelope_weight > 0
+        if env:
+            if node is None:  # the constant cost as per-node arrays, so that the penalty gradient has a place to go
+                ws["env_glin"].zero_()
+                node = (ws["env_q"], ws["env_xref"], ws["env_glin"])
+            self._envelope_model(X, glin=node[2])  # before the costate: the multipliers see the penalty too
         if self.hessian_mode == "exact":
             self.costate(X, ws["A"], node, out=ws["Lam"])
             Hz = self.hessian(X, U, ws["Lam"], out=ws["Hz"])
+        elif env:
+            Hz = ws["Hz"].zero_()
+        if env:
+            self._envelope_model(X, Hz=Hz)
         self.backward(X, U, ws["A"], ws["Bm"], out=(ws["K"], ws["kff"], ws["dV"]), Hz=Hz, node=node)
         self.forward(x0, X, U, ws["K"], ws["kff"], out=(ws["Xc"], ws["Uc"]))
         self.trajectory_cost(ws["Xc"], ws["Uc"], out=ws["Jc"])
         self.trajectory_cost(X, U, out=ws["J0"])
+        if env:
+            self.envelope_cost(ws["Xc"], ws["Jc"])
+            self.envelope_cost(X, ws["J0"])
         Jc = ws["Jc"].view(na, B)
         Jc = torch.where(torch.isfinite(Jc), Jc, torch.full_like(Jc, float("inf")))
         best, idx = Jc.min(dim=0)

@@ -344,6 +344,93 @@ __global__ __launch_bounds__(kBlock) void k_envelope(const DevParams P, const fl
     }
 }
 
+// ---- the envelope as a soft constraint of the batched solver (the state_constraint role,
+// control/aircraft.py:44-59; IPOPT enforces the rows, the iLQR sweep penalises their violation) -----------------------
+//   penalty_k(x) = w sum_r max(0, g_r(x) - hi_r)^2 + max(0, lo_r - g_r(x))^2
+struct EnvelopePenalty {
+    float lo[4], hi[4];  // bounds of (|v_rel|^2, beta, alpha, z): Aircraft.ENVELOPE_BOUNDS
+    float weight;
+};
+
+// signed violation of row r (0 inside the bounds)
+AC_DI float envelope_violation(const EnvelopePenalty& E, int r, float g) {
+    return g > E.hi[r] ? g - E.hi[r] : (g < E.lo[r] ? g - E.lo[r] : 0.f);
+}
+
+// cost[b] += sum_k penalty_k(x_k), k = 0..H: one lane per instance (X [H+1][13][B])
+template <int INST = 0>
+__global__ __launch_bounds__(kBlock) void k_envelope_cost(const DevParams P, const EnvelopePenalty E,
+                                                          const float* __restrict__ X, long B, long H,
+                                                          float* __restrict__ cost) {
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B) return;
+    float acc = 0.f;
+    for (long k = 0; k <= H; ++k) {
+        float x[13];
+        load_rows<13>(X + k * 13 * B, B, i, x);
+        AeroPre<float> a;
+        aero_pre(P, x, a);
+        const float g[4] = {a.vr[0] * a.vr[0] + a.vr[1] * a.vr[1] + a.vr[2] * a.vr[2], a.beta, a.alpha, x[2]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float v = envelope_violation(E, r, g[r]); acc = fmaf(v, v, acc); }
+    }
+    cost[i] += E.weight * acc;
+}
+
+// Quadratic model of the penalty around the iterate, in the form the backward pass consumes: the gradient
+// 2 w sum_r viol_r grad g_r is ADDED to node_glin [H+1][13][B]; the Gauss-Newton curvature 2 w sum_{r violated} grad g_r grad g_r'
+// is ADDED to the (x, x) block of Hz [H][21][21][B] (nodes k < H; the terminal node keeps the gradient only).
+// One lane per (node, instance).
+template <int INST = 0>
+__global__ __launch_bounds__(kBlock) void k_envelope_model(const DevParams P, const EnvelopePenalty E,
+                                                           const float* __restrict__ X, long B, long H,
+                                                           float* __restrict__ node_glin, float* __restrict__ Hz) {
+    const long t = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (H + 1) * B) return;
+    const long k = t / B, b = t % B;
+    float xv[13];
+    load_rows<13>(X + k * 13 * B, B, b, xv);
+    typedef Dual<7> T;
+    T x[13];
+#pragma unroll
+    for (int r = 0; r < 13; ++r) { x[r] = T(xv[r]); if (r >= 3 && r < 10) x[r].d[r - 3] = 1.f; }
+    AeroPre<T> a;
+    aero_pre(P, x, a);
+    const T row[3] = {a.vr[0] * a.vr[0] + a.vr[1] * a.vr[1] + a.vr[2] * a.vr[2], a.beta, a.alpha};
+    float viol[4], grad[4][13];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        viol[r] = envelope_violation(E, r, r < 3 ? row[r].v : xv[2]);
+#pragma unroll
+        for (int j = 0; j < 13; ++j) grad[r][j] = r < 3 ? ((j >= 3 && j < 10) ? row[r].d[j - 3] : 0.f) : (j == 2 ? 1.f : 0.f);
+    }
+    const float w2 = 2.0f * E.weight;
+    if (node_glin) {
+        float* gl = node_glin + k * 13 * B + b;
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s = fmaf(viol[r], grad[r][j], s);
+            if (s != 0.f) gl[(long)j * B] += w2 * s;
+        }
+    }
+    if (k < H && Hz) {
+        float* hz = Hz + k * 441 * B + b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (viol[r] == 0.f) continue;
+#pragma unroll
+            for (int i = 0; i < 13; ++i)
+#pragma unroll
+                for (int j = 0; j < 13; ++j) {
+                    const float v = grad[r][i] * grad[r][j];
+                    if (v != 0.f) hz[(long)(i * 21 + j) * B] += w2 * v;
+                }
+        }
+    }
+}
+
 // ---- quaternion rows of ControlProblem.state_constraint (control/base.py:285-304) on the NEXT node ------------------
 //   mode 0 ('constraint'):  row = q . q - 1
 //   mode 1 ('baumgarte'):   row = 2 a phi_dot + b^2 phi,  phi = q . q - 1,  phi_dot = 2 q . q_dot,  a = b = 2   (:296-301)

@@ -850,6 +850,40 @@ int ac_shoot_envelope_f32(ac_handle* h, const float* X, long B, long H, float* r
     return envelope_impl(h, X, B * H, B > 0 ? B : 1, rows, Jx, stream);
 }
 
+static EnvelopePenalty to_dev_penalty(const ac_envelope_penalty* p) {
+    EnvelopePenalty d;
+    static_assert(sizeof(EnvelopePenalty) == sizeof(ac_envelope_penalty), "ac_envelope_penalty layout");
+    memcpy(&d, p, sizeof(d));
+    return d;
+}
+
+int ac_envelope_cost_f32(ac_handle* h, const ac_envelope_penalty* pen, const float* X, long B, long H, float* cost,
+                         void* stream) {
+    AC_ENTER(h);
+    if (h && B == 0) return AC_OK;
+    if (!h || !pen || !X || !cost || B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    if (h->dp.p.model_kind == AC_MODEL_QUAD) return fail(AC_ERR_UNSUPPORTED, "envelope rows are the fixed-wing plugin's (control/aircraft.py)");
+    const int grid = (int)((B + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_envelope_cost<0>, grid, kBlock, 0, (hipStream_t)stream, h->dp, to_dev_penalty(pen), X, B, H, cost);
+    note_launch(h, "k_envelope_cost", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_envelope_model_f32(ac_handle* h, const ac_envelope_penalty* pen, const float* X, long B, long H, float* node_glin,
+                          float* Hz, void* stream) {
+    AC_ENTER(h);
+    if (h && B == 0) return AC_OK;
+    if (!h || !pen || !X || (!node_glin && !Hz) || B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    if (h->dp.p.model_kind == AC_MODEL_QUAD) return fail(AC_ERR_UNSUPPORTED, "envelope rows are the fixed-wing plugin's (control/aircraft.py)");
+    const long n = (H + 1) * B;
+    const int grid = (int)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_envelope_model<0>, grid, kBlock, 0, (hipStream_t)stream, h->dp, to_dev_penalty(pen), X, B, H, node_glin, Hz);
+    note_launch(h, "k_envelope_model", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
 int ac_quat_rows_f32(ac_handle* h, int mode, const float* X, const float* Xdot, const float* Fx, const float* Fu, long B,
                      long H, float* row, float* Jx, float* Ju, void* stream) {
     AC_ENTER(h);

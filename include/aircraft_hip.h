@@ -154,6 +154,18 @@ int ac_shoot_derivative_sens_f32(ac_handle* h, const float* X, const float* U, l
 int ac_envelope_f32(ac_handle* h, const float* X, long n, float* rows, float* Jx, void* stream);
 int ac_shoot_envelope_f32(ac_handle* h, const float* X, long B, long H, float* rows, float* Jx, void* stream);
 
+/* The envelope as a SOFT constraint of the batched solver sweep (build-side, SURVEY §8 f1: the state_constraint role of
+ * control/aircraft.py:44-59 — IPOPT enforces the rows, the iLQR sweep penalises their violation):
+ *   penalty(x) = weight * sum_r max(0, g_r(x) - hi_r)^2 + max(0, lo_r - g_r(x))^2,   g = (|v_rel|^2, beta, alpha, z)
+ * ac_envelope_cost_f32:   cost[b] += sum_{k=0..H} penalty(x_k)            X [H+1][13][B], cost [B]
+ * ac_envelope_model_f32:  its quadratic model around X for the backward pass: node_glin [H+1][13][B] += 2 w sum_r viol_r grad g_r,
+ *                         Hz [H][21][21][B] (x,x block) += 2 w sum_{r violated} grad g_r grad g_r'  (either of node_glin, Hz may be NULL). */
+typedef struct ac_envelope_penalty { float lo[4], hi[4], weight; } ac_envelope_penalty;
+int ac_envelope_cost_f32(ac_handle* h, const ac_envelope_penalty* pen, const float* X, long B, long H, float* cost,
+                         void* stream);
+int ac_envelope_model_f32(ac_handle* h, const ac_envelope_penalty* pen, const float* X, long B, long H, float* node_glin,
+                          float* Hz, void* stream);
+
 /* Quaternion rows of ControlProblem.state_constraint on H nodes of X [>=H][13][B] (control/base.py:285-304):
  *   mode 0 ('constraint'):  row = q . q - 1                                                        (:285-286)
  *   mode 1 ('baumgarte'):   row = 2 a phi_dot + b^2 phi,  phi = q . q - 1,  phi_dot = 2 q . q_dot,  a = b = 2   (:288-304)

@@ -219,3 +219,69 @@ def test_receding_horizon_loop_matches_numpy_restatement(gpu, warm_start, iterat
         assert not loop.U.cpu().numpy().any()
     if iterations:
         assert all((c >= 0).any() for ch in choices for c in ch)  # the solver did move the iterate in every cycle
+
+
+def _envelope_numpy(orc, X, lo, hi, w):
+    """penalty cost (B,), gradient (H+1, 13, B) and Gauss-Newton curvature (H+1, 13, 13, B) from the oracle's rows / Jx"""
+    Hn, _, B = X.shape
+    cost = np.zeros(B); grad = np.zeros((Hn, 13, B)); curv = np.zeros((Hn, 13, 13, B))
+    for k in range(Hn):
+        rows, Jx = orc.envelope(X[k])
+        viol = np.where(rows > hi[:, None], rows - hi[:, None], np.where(rows < lo[:, None], rows - lo[:, None], 0.0))
+        cost += w * (viol ** 2).sum(axis=0)
+        grad[k] = 2 * w * np.einsum("rb,rjb->jb", viol, Jx)
+        act = (viol != 0).astype(float)
+        curv[k] = 2 * w * np.einsum("rb,rib,rjb->ijb", act, Jx, Jx)
+    return cost, grad, curv
+
+
+def test_envelope_penalty_kernels_match_numpy(gpu):
+    """ac_envelope_cost_f32 / ac_envelope_model_f32 — the soft form of AircraftControl.state_constraint
+    (control/aircraft.py:44-59) the batched sweep uses — against the oracle's envelope rows and their exact Jacobian."""
+    import torch
+    from aircraft_amd.control import ILQR
+    from tests.helpers import synthetic_problem
+
+    ac, il0, cost, X0, U = setup(gpu, "poly", None, B=40, H=12)
+    il = ILQR(system=ac, dt=0.01, num_nodes=12, cost=cost, alphas=(1.0, 0.5), envelope_weight=3.0,
+              envelope_bounds=((45.0 ** 2, 60.0 ** 2), (-0.01, 0.01), (-0.02, 0.03), (-1e30, -199.5)))  # tight: many rows active
+    Xs, Us = synthetic_problem(40, 12, seed=3)
+    X = il.rollout(dev(X0, gpu), dev(0.3 * Us, gpu))
+    Xh = X.cpu().numpy().astype(np.float64)
+    lo = np.array([b[0] for b in il.envelope_bounds]); hi = np.array([b[1] for b in il.envelope_bounds])
+    cw, gw, pw = _envelope_numpy(make_oracle(ac), Xh, lo, hi, 3.0)
+    assert (cw > 0).mean() > 0.5  # the test is not vacuous
+    J = torch.full((40,), 7.0, device=gpu)
+    il.envelope_cost(X, J)
+    assert np.abs(J.cpu().numpy() - 7.0 - cw).max() <= 2e-5 * max(cw.max(), 1.0)
+    glin = torch.zeros((13, 13, 40), device=gpu); Hz = torch.zeros((12, 21, 21, 40), device=gpu)
+    il._envelope_model(X, glin=glin, Hz=Hz)
+    assert np.abs(glin.cpu().numpy() - gw).max() <= 5e-5 * max(np.abs(gw).max(), 1.0)
+    Hh = Hz.cpu().numpy()
+    assert np.abs(Hh[:, :13, :13] - pw[:12]).max() <= 1e-4 * max(np.abs(pw).max(), 1.0)
+    assert not Hh[:, 13:].any() and not Hh[:, :, 13:].any()
+
+
+def test_envelope_penalty_steers_the_solve(gpu):
+    """With the envelope as a soft constraint the solve trades goal cost for staying inside: gliders asked to reach a goal
+    far below their glide path exceed the alpha bound without the penalty and stay (nearly) inside with it."""
+    from aircraft_amd.control import ILQR, QuadraticCost
+
+    ac, il0, cost, X0, U = setup(gpu, "poly", None, B=48, H=40)
+    cost = QuadraticCost.goal((24.0, 0.0), w_goal=1.0, height=-185.0, w_height=40.0, w_lateral_speed=0.1, r=0.02, reg=1.0)
+    bounds = ((20.0 ** 2, 100.0 ** 2), (-np.deg2rad(10), np.deg2rad(10)), (-np.deg2rad(4), np.deg2rad(4)), (-1e30, 0.0))
+    res = {}
+    for w in (0.0, 2e6):
+        il = ILQR(system=ac, dt=0.01, num_nodes=40, cost=cost, alphas=(1.0, 0.5, 0.25, 0.1), envelope_weight=w,
+                  envelope_bounds=bounds)
+        X, Uo, hist = il.solve(dev(X0, gpu), dev(np.zeros_like(U), gpu), iters=8)
+        rows, _ = il.envelope(X)
+        alpha = rows[:, 2].abs().amax(dim=0).cpu().numpy()
+        h = hist.cpu().numpy()
+        assert np.isfinite(h).all() and (np.diff(h, axis=0) <= 1e-5 * np.abs(h[:-1]) + 1e-5).all()  # monotone incl. the penalty
+        res[w] = alpha
+    lim = np.deg2rad(4)
+    assert (res[0.0] > 1.3 * lim).mean() > 0.5          # unconstrained: most instances leave the alpha bound by > 30 %
+    # penalised (quadratic penalty, weight 2e6: measured median 1.06 x the bound, 0.126 / 0.088 rad at 2e4 / 2e5)
+    assert (res[2e6] < 1.15 * lim).mean() > 0.9
+    assert np.median(res[2e6]) < 0.5 * np.median(res[0.0])
