@@ -14,6 +14,14 @@ OBJ = os.path.join(_HERE, "csrc", "_obj")
 OUT = os.path.join(_HERE, "libaircraft_hip.so")
 HEADERS = glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(_HERE, "..", "include", "aircraft_hip.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-pass-failed", "-ffp-contract=on"]
+# Per-unit flags of the headline kernels (k_nn_step_sens<8,true> and its wave-pair twin own the whole 512-register file):
+# two output tiles per accumulator chunk instead of four and SLP packing only where it is clearly profitable bring the
+# register-spill scratch from 228 to 36 B/lane (HBM traffic 1.9x -> 1.1x of the algorithmic bytes) at +0.6 % speed
+# (same-box A/Bs).  Results are bit-identical: neither changes the order of any accumulation.
+UNIT_FLAGS = {
+    "nn_inst_wt8_mfma_sens": ["-DAC_CH=2", "-mllvm", "-slp-threshold=6"],
+    "nn_inst_wt8_mfma_pair": ["-DAC_CH=2", "-mllvm", "-slp-threshold=6"],
+}
 
 
 def sources():
@@ -43,12 +51,12 @@ def _build(force, verbose, jobs, OBJ, OUT, CFLAGS) -> str:
     for src in sources():
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or _stale(obj, [src] + HEADERS):
+        if force or _stale(obj, [src] + HEADERS + [os.path.abspath(__file__)]):
             todo.append((src, obj))
 
     def cc(job):
         src, obj = job
-        cmd = ["hipcc", *CFLAGS, "-c", src, "-o", obj]
+        cmd = ["hipcc", *CFLAGS, *UNIT_FLAGS.get(os.path.basename(src)[:-4], []), "-c", src, "-o", obj]
         if verbose:
             print("[aircraft_amd.build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

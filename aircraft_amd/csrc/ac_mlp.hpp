@@ -137,7 +137,10 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
     AC_DI int input_of(int i) const { if constexpr (NSLAB <= 10) return tri(i); else return i; }
     static constexpr bool kTangent = TANGENT;
     static constexpr bool kDeriv = TANGENT || SECOND;  // slabs > 0 are derivative slabs (no bias, chain-rule epilogue)
-    static constexpr int CH = WT < 4 ? WT : 4;  // output tiles computed together (independent accumulators)
+#ifndef AC_CH
+#define AC_CH 4  // the two headline units are built with 2 (build.py UNIT_FLAGS): 84 % less spill, DESIGN.md §6
+#endif
+    static constexpr int CH = WT < AC_CH ? WT : AC_CH;  // output tiles computed together (independent accumulators)
 
     float a[NSLAB][WT][4];
     const MlpPlan& plan;
