@@ -137,6 +137,9 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
     AC_DI int input_of(int i) const { if constexpr (NSLAB <= 10) return tri(i); else return i; }
     static constexpr bool kTangent = TANGENT;
     static constexpr bool kDeriv = TANGENT || SECOND;  // slabs > 0 are derivative slabs (no bias, chain-rule epilogue)
+    // The last layer (width -> 6) of the sensitivity engines runs on the vector ALUs (last_valu below): as an MFMA tile it uses
+    // 6 of 16 output rows.  Such engines take the handle's `plan_sens`, whose last-layer block holds [bias][wlt] only.
+    static constexpr bool kVLast = TANGENT && USE_MFMA;
 #ifndef AC_CH
 #define AC_CH 4  // the two headline units are built with 2 (build.py UNIT_FLAGS): 84 % less spill, DESIGN.md §6
 #endif
@@ -150,9 +153,20 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
     int ring_pos;  // number of streamed layers consumed so far (slot = ring_pos & 1)
     int snext;     // position in plan.streamed[] of the next layer to fetch (wraps: the sequence is cyclic)
     Stamper st;    // diagnostic flavor only (empty otherwise)
+    // Spread mode (the six-slab sensitivity engine at width 128 with two-tile chunks: 24 chunks per hidden layer): the next
+    // streamed layer's LDS-DMA is issued one 1-KiB piece per chunk of the current layer's matrix stream instead of as a burst
+    // of 17 pieces behind the barrier — the burst delayed the first blocks' ds_reads (+0.4 % on the headline; with four-tile
+    // chunks the same change cost 500-1000 B of scratch per lane).  All three fields are wave-uniform.
+    static constexpr bool kSpread = TANGENT && NSLAB * (WT / CH) * 4 >= WT * WT + 1;
+    const char* dma_src;
+    unsigned dma_dst;
+    int dma_last;  // last piece of the pending copy.  Until acquire() meets a streamed layer (all-resident nets: never) the
+                   // pending copy is piece 0 of the resident first layer ONTO ITSELF: same bytes, so the issue points need no
+                   // branch (a wave-uniform test around them costs 370 B of scratch per lane in the headline kernel)
 
     AC_DI MlpEngine(const MlpPlan& pl, const float* blob, char* lds_base)
-        : plan(pl), gblob(blob), lds(lds_base), ring_pos(0), snext(pl.n_streamed > 1 ? 1 : 0) {
+        : plan(pl), gblob(blob), lds(lds_base), ring_pos(0), snext(pl.n_streamed > 1 ? 1 : 0),
+          dma_src((const char*)(blob + pl.g_off[0])), dma_dst((unsigned)pl.lds_off[0]), dma_last(0) {
         lane = threadIdx.x & 63; g = lane >> 4; wave = threadIdx.x >> 6; nwaves = blockDim.x >> 6;
     }
 
@@ -211,6 +225,17 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
         // The chunks of a layer are mutually independent; without a fence the machine scheduler interleaves
         // them across the whole straight-line layer and the live accumulators no longer fit the register file.
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kSpread && KT == WT && NT == WT) {
+            const int ord = s * (NT / CNT) + nc / CNT;  // compile-time ordinal of this chunk within the layer
+            if (ord * 4 < WT * WT + 1 + 3) {
+                int pc = __builtin_amdgcn_readfirstlane(wave) + 4 * ord;
+                pc = pc < dma_last ? pc : dma_last;  // past the end: repeat the last piece (same bytes, harmless)
+                const char* base = dma_src + ((long)pc << 10);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (unsigned)lane * 16u),
+                                                 (__attribute__((address_space(3))) void*)(lds + dma_dst + (pc << 10)), 16, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         f32x4 acc[CNT];
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
@@ -342,6 +367,55 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
     // slabs of the first layer are just columns of W0 scaled by act'(h) — W0[n][j] (1 - h_n^2) — so they are read
     // from a transposed copy of W0 the host appends to the block, with no MFMA at all (saves 5/6 of this layer's
     // matrix work, 3 % of a stage).
+    // The first layer of the sensitivity engines on the vector ALUs as well: the tangent slabs already read the five columns of
+    // W0 (transposed copy, see layer_first), so the value pre-activation is five more packed FMAs on the same registers
+    // instead of a padded k-tile on the matrix core and a trip through the accumulators.  Four tiles at a time: eight
+    // independent chains.  Products enter in the matrix form's order (z0, z4, z1, z2, z3).
+    AC_DI void first_valu(const char* wl, const float z[5]) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x4* bias4 = reinterpret_cast<const f32x4*>(wl + WT * 1024);
+        const f32x4* w0t = reinterpret_cast<const f32x4*>(wl + WT * 1024 + 1024);  // [5][16*WT] floats
+        const f32x2 z01 = {z[0], z[1]}, z23 = {z[2], z[3]}, z4x = {z[4], 0.f};
+        constexpr int TB = WT < 4 ? WT : 4;
+#pragma unroll
+        for (int n0 = 0; n0 < WT; n0 += TB) {
+            f32x4 w[TB][5], b[TB];
+#pragma unroll
+            for (int i = 0; i < TB; ++i) {
+                b[i] = bias4[(n0 + i) * 4 + g];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) w[i][j] = w0t[j * (WT * 4) + 4 * (n0 + i) + g];
+            }
+            f32x2 pre[TB][2];
+#pragma unroll
+            for (int i = 0; i < TB; ++i) { pre[i][0] = f32x2{b[i][0], b[i][1]}; pre[i][1] = f32x2{b[i][2], b[i][3]}; }
+#pragma unroll
+            for (int step = 0; step < 5; ++step) {
+                constexpr int order[5] = {0, 4, 1, 2, 3};
+                const int j = order[step];
+#pragma unroll
+                for (int i = 0; i < TB; ++i)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const f32x2 wp = {w[i][j][2 * hh], w[i][j][2 * hh + 1]};
+                        const f32x2 zp = j < 2 ? z01 : (j < 4 ? z23 : z4x);
+                        if (j & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(pre[i][hh]) : "v"(wp), "v"(zp));
+                        else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(pre[i][hh]) : "v"(wp), "v"(zp));
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < TB; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float h = act_tanh(pre[i][r >> 1][r & 1]);
+                    a[0][n0 + i][r] = h;
+                    const float sp = fmaf(-h, h, 1.0f);
+#pragma unroll
+                    for (int j = 0; j < kTangents; ++j) a[1 + j][n0 + i][r] = w[i][TOFF + j][r] * sp;
+                }
+        }
+    }
+
     AC_DI void layer_first(const char* wl) {
         constexpr bool act = true;  // not the last layer (see forward()): always tanh after the host-side fold
         const f32x4* wf = reinterpret_cast<const f32x4*>(wl) + lane;
@@ -402,6 +476,126 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
         }
     }
 
+    // Last layer of a multi-layer net, width -> 6, on the vector ALUs.  A lane holds 4 WT of its unit's 16 WT neurons per slab
+    // (rows 16 t + 4 g + r), so it forms the partial sums of the 6 outputs over those with v_pk_fma_f32 (accumulator pair =
+    // outputs (2 kp, 2 kp + 1); the activation register is broadcast to both halves by op_sel), 12 WT per slab against the
+    // 4 WT exposed MFMAs (of 32 cycles) of the matrix form; the four lanes of a unit are then summed, and the total handed to
+    // all four, by unit_totals4 above.  wl: the block [bias 1 KiB]
+    // [wlt: per (tile t, lane group g) six float4 {W[2kp][n], W[2kp+1][n], W[2kp][n+1], W[2kp+1][n+1]}, n = 16t+4g+2rp, index
+    // (t*4+g)*6 + 2 kp + rp] the host packs (ac_set_mlp).  Outputs go straight to y / J: no output tile, no broadcast.
+    // Totals of four per-lane values over the four lanes of a unit (lanes col, col + 16, col + 32, col + 48), handed to all
+    // four: a reduce-scatter by v_permlane32_swap / v_permlane16_swap (two values per swap) and the mirror-image all-gather —
+    // 12 swaps and 3 adds for four values, every total formed once (the four lanes hold the same bits).
+    AC_DI static void unit_totals4(float (&v)[4]) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        auto sw32 = [](float p, float q, float& lo, float& hi) {
+            const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(q), false, false);
+            lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+        };
+        auto sw16 = [](float p, float q, float& lo, float& hi) {
+            const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(q), false, false);
+            lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+        };
+        float l0, h0, l1, h1;
+        sw32(v[0], v[1], l0, h0);  // rows (0, 1) now carry v0's halves, rows (2, 3) v1's
+        sw32(v[2], v[3], l1, h1);
+        const float w0 = l0 + h0, w1 = l1 + h1;
+        float l2, h2;
+        sw16(w0, w1, l2, h2);
+        const float u = l2 + h2;   // row 0: total of v0, row 1: v2, row 2: v1, row 3: v3
+        float e, o;
+        sw16(u, u, e, o);          // e = rows (0, 0, 2, 2) of u, o = rows (1, 1, 3, 3)
+        sw32(e, e, v[0], v[1]);
+        sw32(o, o, v[2], v[3]);
+    }
+
+    template <int JC> AC_DI void last_valu(const char* wl, int act, float y[6], float (*J)[JC]) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x4* wv = reinterpret_cast<const f32x4*>(wl + 1024) + g * 6;
+        const float* bias = reinterpret_cast<const float*>(wl);
+        float sp[6];
+        // two slabs at a time, even and odd rows on accumulators of their own: twelve independent chains (a dependent
+        // v_pk_fma_f32 issues ~38 cycles after its producer, profiles/r02_micro_pkfma_banks.txt), and a slab's 4 WT activation
+        // registers are dead once its group is done (all six slabs at once: 100 B of scratch per lane)
+#pragma unroll
+        for (int s0 = 0; s0 < NSLAB; s0 += 2) {
+            constexpr int kGroup = 2;
+            f32x2 acc[kGroup][3][2];
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i)
+#pragma unroll
+                for (int kp = 0; kp < 3; ++kp) acc[i][kp][0] = acc[i][kp][1] = f32x2{0.f, 0.f};
+            f32x4 w[2][6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w[0][i] = wv[i];
+#pragma unroll
+            for (int t = 0; t < WT; ++t) {
+                if (t + 1 < WT) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) w[(t + 1) & 1][i] = wv[(t + 1) * 24 + i];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 (&wc)[6] = w[t & 1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < kGroup; ++i) {
+                        if (s0 + i >= NSLAB) continue;
+                        const f32x2 ap = {a[s0 + i][t][r & 2], a[s0 + i][t][(r & 2) + 1]};
+#pragma unroll
+                        for (int kp = 0; kp < 3; ++kp) {
+                            const f32x4 wq = wc[2 * kp + (r >> 1)];
+                            const f32x2 wp = (r & 1) ? f32x2{wq[2], wq[3]} : f32x2{wq[0], wq[1]};
+                            if (r & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[i][kp][1]) : "v"(ap), "v"(wp));
+                            else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[i][kp][0]) : "v"(ap), "v"(wp));
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float p[kGroup][6];
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i)
+#pragma unroll
+                for (int kp = 0; kp < 3; ++kp) {
+                    const f32x2 sum = acc[i][kp][0] + acc[i][kp][1];
+                    p[i][2 * kp] = sum[0]; p[i][2 * kp + 1] = sum[1];
+                }
+            const bool two = s0 + 1 < NSLAB;
+            {
+                float q[4] = {p[0][0], p[0][1], p[0][2], p[0][3]};
+                unit_totals4(q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) p[0][k] = q[k];
+            }
+            if (two) {
+                float q[4] = {p[1][0], p[1][1], p[1][2], p[1][3]};
+                unit_totals4(q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) p[1][k] = q[k];
+            }
+            {
+                float q[4] = {p[0][4], p[0][5], two ? p[1][4] : 0.f, two ? p[1][5] : 0.f};
+                unit_totals4(q);
+                p[0][4] = q[0]; p[0][5] = q[1]; p[1][4] = q[2]; p[1][5] = q[3];
+            }
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i) {
+                const int sl = s0 + i;
+                if (sl >= NSLAB) continue;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    if (sl == 0) {
+                        const float pre = p[i][k] + bias[k];
+                        y[k] = act ? act_tanh(pre) : pre;
+                        sp[k] = act ? fmaf(-y[k], y[k], 1.0f) : 1.0f;
+                    } else {
+                        J[k][sl - 1] = sp[k] * p[i][k];
+                    }
+                }
+            }
+        }
+    }
+
     // LDS address of layer l's block; for a streamed layer: wait for its DMA, then (the barrier having
     // proven every wave is done with the other slot) request the next streamed layer into that slot.
     AC_DI const char* acquire(int l) {
@@ -411,8 +605,14 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
         const char* wl = lds + plan.ring_off[ring_pos & 1];
         const int nl = plan.streamed[snext];  // one scalar load (was: a scan of lds_off[] and a modulo per call)
         snext = (snext + 1 == plan.n_streamed) ? 0 : snext + 1;
-        lds_dma_copy(gblob + plan.g_off[nl], lds + plan.ring_off[(ring_pos + 1) & 1], plan.bytes[nl], wave, nwaves,
-                     lane);
+        if constexpr (kSpread) {
+            dma_src = (const char*)(gblob + __builtin_amdgcn_readfirstlane(plan.g_off[nl]));
+            dma_dst = (unsigned)__builtin_amdgcn_readfirstlane(plan.ring_off[(ring_pos + 1) & 1]);
+            dma_last = __builtin_amdgcn_readfirstlane((plan.bytes[nl] >> 10) - 1);
+        } else {
+            lds_dma_copy(gblob + plan.g_off[nl], lds + plan.ring_off[(ring_pos + 1) & 1], plan.bytes[nl], wave, nwaves,
+                         lane);
+        }
         ++ring_pos;
         return wl;
     }
@@ -470,7 +670,7 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
                 layer<1, 1>(acquire(0), plan.act[0]);
             }
         } else {
-            layer_first(acquire(0));
+            if constexpr (kVLast) first_valu(acquire(0), z); else layer_first(acquire(0));
             AC_MARK(st, 2);  // [2] first layer
 #pragma nounroll
             for (int l = 1; l < L - 1; ++l) {
@@ -479,7 +679,12 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
                 layer<WT, WT, 1>(wl, 1);  // tanh on every layer but the last: ac_set_mlp folds activation-free layers away
                 AC_MARK(st, 4);  // [4] hidden layer GEMM + epilogues
             }
-            if constexpr (SECOND) {  // as for L == 1: no runtime activation flag inside the second-order epilogues
+            if constexpr (kVLast) {
+                last_valu<JC>(acquire(L - 1), plan.act[L - 1], y, J);
+                AC_MARK(st, 5);  // [5] last layer
+                AC_MARK(st, 6);
+                return;
+            } else if constexpr (SECOND) {  // as for L == 1: no runtime activation flag inside the second-order epilogues
                 const char* wll = acquire(L - 1);
                 if (plan.act[L - 1]) layer<WT, 1, 1>(wll, 1); else layer<WT, 1, 0>(wll, 0);
             } else {

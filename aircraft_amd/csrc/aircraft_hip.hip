@@ -67,6 +67,7 @@ struct ac_handle {
     bool no_pair;  // AIRCRAFT_HIP_NO_PAIR=1 (measurement aid): never route a remainder to k_nn_step_sens_pair
     bool has_linear, has_poly, has_mlp;
     MlpPlan plan;
+    MlpPlan plan_sens;  // the MFMA sensitivity engines' plan: last layer = [bias][wlt] for MlpEngine::last_valu (ac_set_mlp)
     int wt;         // register tiles per slab the plan needs (2, 4 or 8)
     int use_mfma;
     float* d_blob;  // packed MLP weights + biases (device)
@@ -174,14 +175,19 @@ void launch_hess(ac_handle* h, hipStream_t st, const float* X, const float* U, f
     } while (0)
 
 // Instantiate an NN kernel template for the (WT, MFMA) the handle needs.
-#define AC_NN_CASE(WT_, MF_, KERNEL_EXPR, GRID, BLOCK, ...)                                          \
+#define AC_NN_CASE_PLAN(PLAN_, WT_, MF_, KERNEL_EXPR, GRID, BLOCK, ...)                                \
     if (h->wt == WT_ && (h->use_mfma != 0) == MF_) {                                                 \
         auto kern = KERNEL_EXPR;                                                                     \
-        int rc_ = set_lds_limit(h, kern, h->plan.lds_total);                                            \
+        int rc_ = set_lds_limit(h, kern, (PLAN_).lds_total);                                         \
         if (rc_ != AC_OK) return rc_;                                                                \
-        hipLaunchKernelGGL(kern, GRID, BLOCK, h->plan.lds_total, st, h->dp, h->plan, h->d_blob, __VA_ARGS__); \
+        hipLaunchKernelGGL(kern, GRID, BLOCK, (PLAN_).lds_total, st, h->dp, PLAN_, h->d_blob, __VA_ARGS__); \
         launched = true;                                                                             \
     }
+#define AC_NN_CASE(WT_, MF_, KERNEL_EXPR, GRID, BLOCK, ...) AC_NN_CASE_PLAN(h->plan, WT_, MF_, KERNEL_EXPR, GRID, BLOCK, __VA_ARGS__)
+// the six-slab sensitivity kernels: the matrix-core flavour runs its last layer on the vector ALUs and takes plan_sens
+#define AC_NN_CASE_SENS(WT_, MF_, KERNEL_EXPR, GRID, BLOCK, ...)                                      \
+    if (MF_) { AC_NN_CASE_PLAN(h->plan_sens, WT_, MF_, KERNEL_EXPR, GRID, BLOCK, __VA_ARGS__) }       \
+    else { AC_NN_CASE_PLAN(h->plan, WT_, MF_, KERNEL_EXPR, GRID, BLOCK, __VA_ARGS__) }
 
 }  // namespace
 
@@ -332,6 +338,7 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
     const int maxt = (maxh + 15) / 16;
     const int wt = maxt <= 2 ? 2 : (maxt <= 4 ? 4 : 8);
     size_t total_floats = 0;
+    const int wlt_bytes = ((wt * 384 + 1023) / 1024) * 1024;  // [wt tiles][4 lane groups][6 float4], whole LDS-DMA pieces
     for (int l = 0; l < n_layers; ++l) {
         pl.KT[l] = (l == 0) ? 1 : wt;
         pl.NT[l] = (l == n_layers - 1) ? 1 : wt;
@@ -341,6 +348,9 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
         if (l == 0 && n_layers > 1) pl.bytes[l] += ((5 * wt * 64 + 1023) / 1024) * 1024;
         pl.g_off[l] = (int)total_floats;
         total_floats += (size_t)pl.bytes[l] / 4;
+        // last layer of a multi-layer net: + wlt, the per-lane weight pairs of MlpEngine::last_valu — in the global blob only;
+        // plan_sens (below) copies [bias][wlt] to LDS, `pl` the fragments and the bias as before
+        if (l == n_layers - 1 && n_layers > 1) total_floats += (size_t)wlt_bytes / 4;
     }
     // Pack: [nt][kt][lane][4] with lane = col + 16 g -> W[16 nt + col][16 kt + 4 g + j]; then the padded bias.
     std::vector<float> blob(total_floats, 0.f);
@@ -362,9 +372,22 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
             for (int j = 0; j < 5; ++j)
                 for (int n = 0; n < wt * 16; ++n) wt0[j * wt * 16 + n] = n < nout ? fW[(size_t)l][(size_t)n * nin + j] : 0.f;
         }
+        if (l == n_layers - 1 && n_layers > 1) {
+            float* wl = bd + 256;  // after the 1-KiB bias piece
+            auto wv = [&](int k, int n) { return (k < nout && n < nin) ? fW[(size_t)l][(size_t)k * nin + n] : 0.f; };
+            for (int t = 0; t < wt; ++t)
+                for (int g = 0; g < 4; ++g)
+                    for (int kp = 0; kp < 3; ++kp)
+                        for (int rp = 0; rp < 2; ++rp) {
+                            float* q = wl + (size_t)(((t * 4 + g) * 6) + 2 * kp + rp) * 4;
+                            const int n0 = 16 * t + 4 * g + 2 * rp;
+                            q[0] = wv(2 * kp, n0); q[1] = wv(2 * kp + 1, n0); q[2] = wv(2 * kp, n0 + 1); q[3] = wv(2 * kp + 1, n0 + 1);
+                        }
+        }
     }
     // LDS plan: everything resident if it fits; otherwise the largest layers stream through a 2-slot ring.
-    {
+    auto plan_lds = [&](MlpPlan& pl) -> int {
+        pl.n_streamed = 0; pl.first_streamed = -1;
         int total = 0;
         for (int l = 0; l < n_layers; ++l) total += pl.bytes[l];
         for (int l = 0; l < n_layers; ++l) pl.lds_off[l] = 0;
@@ -380,7 +403,7 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
             for (int l = 0; l < n_layers; ++l) if (pl.bytes[l] < big) resident += pl.bytes[l];
             if (resident + 2 * big > kLdsBudget) {
                 snprintf(g_err, sizeof(g_err), "MLP does not fit the LDS plan (%d resident + 2 x %d ring)", resident, big);
-                return AC_ERR_UNSUPPORTED;
+                return (int)AC_ERR_UNSUPPORTED;
             }
             pl.first_streamed = -1;
             for (int l = 0; l < n_layers; ++l) {
@@ -392,6 +415,17 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
         }
         for (int l = 0, i = 0; l < n_layers; ++l)
             if (pl.lds_off[l] < 0) pl.streamed[i++] = l;
+        return AC_OK;
+    };
+    { const int rc = plan_lds(pl); if (rc != AC_OK) return rc; }
+    // plan_sens: the last layer's LDS copy is [bias 1 KiB][wlt] (the blob keeps the MFMA fragments in front of them)
+    MlpPlan ps = pl;
+    if (n_layers > 1) {
+        const int last = n_layers - 1;
+        ps.g_off[last] = pl.g_off[last] + pl.NT[last] * pl.KT[last] * 256;
+        ps.bytes[last] = 1024 + wlt_bytes;
+        const int rc = plan_lds(ps);
+        if (rc != AC_OK) return rc;
     }
     // "MFMA off": weight image of the tiled vector-ALU engine, k-major [K][N] per layer (the last layer transposed [8][K]),
     // hidden widths zero-padded to 32 or 64.  Nets it does not cover (wider than 64, or a single layer after the fold)
@@ -450,6 +484,7 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
     h->d_blob = d;
     h->blob_floats = total_floats;
     h->plan = pl;
+    h->plan_sens = ps;
     h->wt = wt;
     h->use_mfma = use_mfma ? 1 : 0;
     memcpy(h->dp.mlp_in_mean, in_mean, 5 * sizeof(float));
@@ -719,26 +754,26 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
         if (n_main > 0) {
             const int grid = (int)((n_main + 63) / 64);
             bool launched = false;
-            AC_NN_CASE(2, true, (k_nn_step_sens<2, true>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
-            AC_NN_CASE(4, true, (k_nn_step_sens<4, true>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
-            AC_NN_CASE(8, true, (k_nn_step_sens<8, true>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
-            AC_NN_CASE(2, false, (k_nn_step_sens<2, false>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
-            AC_NN_CASE(4, false, (k_nn_step_sens<4, false>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
-            AC_NN_CASE(8, false, (k_nn_step_sens<8, false>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
+            AC_NN_CASE_SENS(2, true, (k_nn_step_sens<2, true>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
+            AC_NN_CASE_SENS(4, true, (k_nn_step_sens<4, true>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
+            AC_NN_CASE_SENS(8, true, (k_nn_step_sens<8, true>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
+            AC_NN_CASE_SENS(2, false, (k_nn_step_sens<2, false>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
+            AC_NN_CASE_SENS(4, false, (k_nn_step_sens<4, false>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
+            AC_NN_CASE_SENS(8, false, (k_nn_step_sens<8, false>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
             if (!launched) return fail(AC_ERR_UNSUPPORTED, "no kernel instance for this MLP width / flavour");
-            note_launch(h, "k_nn_step_sens", grid, kBlock, h->plan.lds_total);
+            note_launch(h, "k_nn_step_sens", grid, kBlock, (h->use_mfma ? h->plan_sens : h->plan).lds_total);
             AC_HIP(hipGetLastError());
         }
         if (n_pair > 0) {
             const int grid_p = (int)((n_pair + 31) / 32);
-            const int lds_p = h->plan.lds_total + 2 * 2 * 16 * 30 * (int)sizeof(float);  // + the pairs' Jacobian exchange
+            const int lds_p = h->plan_sens.lds_total + 2 * 2 * 16 * 30 * (int)sizeof(float);  // + the pairs' Jacobian exchange
             bool launched = false;
 #define AC_PAIR_CASE(WT_)                                                                                              \
             if (h->wt == WT_) {                                                                                        \
                 auto kern = k_nn_step_sens_pair<WT_>;                                                                  \
                 int rc_ = set_lds_limit(h, kern, lds_p);                                                                  \
                 if (rc_ != AC_OK) return rc_;                                                                          \
-                hipLaunchKernelGGL(kern, grid_p, kBlock, lds_p, st, h->dp, h->plan, h->d_blob, X, U, dt, dt_per_unit, n, \
+                hipLaunchKernelGGL(kern, grid_p, kBlock, lds_p, st, h->dp, h->plan_sens, h->d_blob, X, U, dt, dt_per_unit, n, \
                                    blk, Xn, A, Bm, c, n_main);                                                          \
                 launched = true;                                                                                       \
             }
@@ -799,14 +834,14 @@ static int deriv_sens_impl(ac_handle* h, const float* X, const float* U, long n,
     if (h->dp.p.model_kind == AC_MODEL_NN) {
         const int grid = (int)((n + 63) / 64);
         bool launched = false;
-        AC_NN_CASE(2, true, (k_nn_deriv_sens<2, true>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
-        AC_NN_CASE(4, true, (k_nn_deriv_sens<4, true>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
-        AC_NN_CASE(8, true, (k_nn_deriv_sens<8, true>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
-        AC_NN_CASE(2, false, (k_nn_deriv_sens<2, false>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
-        AC_NN_CASE(4, false, (k_nn_deriv_sens<4, false>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
-        AC_NN_CASE(8, false, (k_nn_deriv_sens<8, false>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
+        AC_NN_CASE_SENS(2, true, (k_nn_deriv_sens<2, true>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
+        AC_NN_CASE_SENS(4, true, (k_nn_deriv_sens<4, true>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
+        AC_NN_CASE_SENS(8, true, (k_nn_deriv_sens<8, true>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
+        AC_NN_CASE_SENS(2, false, (k_nn_deriv_sens<2, false>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
+        AC_NN_CASE_SENS(4, false, (k_nn_deriv_sens<4, false>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
+        AC_NN_CASE_SENS(8, false, (k_nn_deriv_sens<8, false>), grid, kBlock, X, U, n, blk, Xdot, Fx, Fu)
         if (!launched) return fail(AC_ERR_UNSUPPORTED, "no kernel instance for this MLP width / flavour");
-        note_launch(h, "k_nn_deriv_sens", grid, kBlock, h->plan.lds_total);
+        note_launch(h, "k_nn_deriv_sens", grid, kBlock, (h->use_mfma ? h->plan_sens : h->plan).lds_total);
         AC_HIP(hipGetLastError());
         return AC_OK;
     }
