@@ -221,7 +221,7 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
     template <int CNT, int KT, int NT, int ACT>
     AC_DI void gemm_chunk(const f32x4* __restrict__ wf, const f32x4* __restrict__ bias4, int s, int nc, f32x4 (&o)[NT],
                           const float (&in)[WT][4], const f32x4 (&oprev)[NT], int act, f32x4 (&wcur)[CNT],
-                          bool prefetch_next_chunk) {
+                          f32x4 (&bcur)[CNT], bool prefetch_next_chunk) {
         // The chunks of a layer are mutually independent; without a fence the machine scheduler interleaves
         // them across the whole straight-line layer and the live accumulators no longer fit the register file.
         __builtin_amdgcn_sched_barrier(0);
@@ -239,7 +239,11 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
         f32x4 acc[CNT];
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
-            if (s == 0 || !kDeriv) acc[i] = bias4[(nc + i) * 4 + g];  // a value slab starts from the bias
+#ifdef AC_BIAS_AT_HEAD
+            if (s == 0 || !kDeriv) acc[i] = bias4[(nc + i) * 4 + g];
+#else
+            if (s == 0 || !kDeriv) acc[i] = bcur[i];  // a value slab starts from the bias (fetched during the previous chunk)
+#endif
             else acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         f32x4 wnext[CNT];
@@ -260,6 +264,12 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
                 const int nkt = last ? 0 : kt + 1;
 #pragma unroll
                 for (int i = 0; i < CNT; ++i) wnext[i] = wf[((nnc + i) * KT + nkt) * 64];
+                // ... and, behind the last block, the bias the next chunk's accumulators start from (read at the head of the
+                // chunk it was one exposed LDS latency per chunk of every value slab: 4 x ~130 cycles per hidden layer)
+                if (last && (kDeriv ? (s == 0 && nc + CNT < NT) : (nc + CNT < NT || s + 1 < NSLAB))) {
+#pragma unroll
+                    for (int i = 0; i < CNT; ++i) bcur[i] = bias4[(nnc + i) * 4 + g];
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -350,12 +360,15 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
         f32x4 wcur[C];   // A fragments of the block about to run; carried across chunks
 #pragma unroll
         for (int i = 0; i < C; ++i) wcur[i] = wf[(i * KT + 0) * 64];
+        f32x4 bcur[C];   // bias of the value-slab chunk about to run
+#pragma unroll
+        for (int i = 0; i < C; ++i) bcur[i] = bias4[i * 4 + g];
 #pragma unroll
         for (int s = 0; s < NSLAB; ++s) {
 #pragma unroll
             for (int nc = 0; nc < NT; nc += C) {
                 const bool more = !(s == NSLAB - 1 && nc + C >= NT);
-                gemm_chunk<C, KT, NT, ACT>(wf, bias4, s, nc, o[s & 1], a[s], o[(s + 1) & 1], act, wcur, more);
+                gemm_chunk<C, KT, NT, ACT>(wf, bias4, s, nc, o[s & 1], a[s], o[(s + 1) & 1], act, wcur, bcur, more);
             }
             if (KT == WT && NT == WT) { if (s == 0) AC_MARK(st, 9); else if (s == 1) AC_MARK(st, 10); else AC_MARK(st, 11); }
         }
