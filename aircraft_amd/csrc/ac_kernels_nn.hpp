@@ -92,10 +92,11 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_deriv_sens(const DevParams P, 
 
 // The sensitivity step for a REMAINDER of units that would leave the last round of the grid half empty: a wave's time
 // is set by its slab count, not by its live columns, so a unit group (16 units) is given to a PAIR of waves — one
-// carries the value slab and tangents 0-2, the other the value slab and tangents 3-4 — and a workgroup holds two
-// groups (32 units).  Both waves run the whole dual RK4 arithmetic on identical inputs (so the pair's results are
-// bit-identical to k_nn_step_sens'); they exchange their Jacobian columns through LDS after every network evaluation;
-// the first wave of the pair stores.  Twice the workgroups, each ~0.73 of the time of a full one.
+// carries the value slab and tangents 0-1, the other tangents 2-4 and NO value slab: it takes the value activations of
+// every hidden layer from its partner through LDS (MlpEngine PAIR roles) — and a workgroup holds two groups (32 units).
+// Both waves run the whole dual RK4 arithmetic on identical inputs (so the pair's results are bit-identical to
+// k_nn_step_sens'); they exchange y and their Jacobian columns through LDS after every network evaluation; the first
+// wave of the pair stores.  Twice the workgroups, each a little over half the time of a full one.
 template <class Engine, int TOFF>
 AC_DI void sens_pair_body(const DevParams& P, const MlpPlan& plan, const float* __restrict__ blob, char* smem,
                           float* xch, bool store, const float* __restrict__ X, const float* __restrict__ U, float dt,
@@ -103,6 +104,7 @@ AC_DI void sens_pair_body(const DevParams& P, const MlpPlan& plan, const float* 
                           float* __restrict__ Xn, float* __restrict__ A, float* __restrict__ Bm,
                           float* __restrict__ c) {
     Engine eng(plan, blob, smem);
+    eng.hx = reinterpret_cast<f32x4*>(smem + plan.lds_total) + pair * (Engine::kWT * 64);
     eng.load_weights();
     const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4;
     const long raw = unit0 + ((long)blockIdx.x * 2 + pair) * 16 + col;
@@ -139,13 +141,14 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_step_sens_pair(const DevParams
                                                                  long unit0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, role = wave & 1, pair = wave >> 1;
-    float* xch = reinterpret_cast<float*>(smem + plan.lds_total) + pair * (2 * 16 * 30);
+    // behind the plan's image: [2 pairs][WT KiB] value activations, then [2 pairs][16 units][36] outputs
+    float* xch = reinterpret_cast<float*>(smem + plan.lds_total + 2 * WT * 1024) + pair * (16 * 36);
     if (role == 0)
-        sens_pair_body<MlpEngine<4, WT, true, true, false, 0>, 0>(P, plan, blob, smem, xch, true, X, U, dt, dt_per_unit, n, blk,
-                                                                   unit0, pair, Xn, A, Bm, c);
+        sens_pair_body<MlpEngine<3, WT, true, true, false, 0, 1>, 0>(P, plan, blob, smem, xch, true, X, U, dt, dt_per_unit, n,
+                                                                      blk, unit0, pair, Xn, A, Bm, c);
     else
-        sens_pair_body<MlpEngine<3, WT, true, true, false, 3>, 3>(P, plan, blob, smem, xch, false, X, U, dt, dt_per_unit, n,
-                                                                   blk, unit0, pair, Xn, A, Bm, c);
+        sens_pair_body<MlpEngine<3, WT, true, true, false, 2, 2>, 2>(P, plan, blob, smem, xch, false, X, U, dt, dt_per_unit, n,
+                                                                      blk, unit0, pair, Xn, A, Bm, c);
 }
 
 template <int WT, bool USE_MFMA, int OP>

@@ -105,11 +105,19 @@ template <> struct TripleHolder<false> {
     AC_DI int tri(int) const { return 0; }
 };
 
-template <int NSLAB, int WT, bool USE_MFMA, bool TANGENT = (NSLAB == 6), bool SECOND = false, int TOFF = 0>
+// PAIR (k_nn_step_sens_pair: two waves share the six slabs of one unit group, three each): 1 = the wave with the value slab and
+// tangents TOFF, TOFF + 1 — it publishes every hidden layer's value activations h through LDS (`hx`); 2 = the wave with three
+// tangent slabs and NO value slab — its hidden-layer outputs stay unscaled until it has read h behind the next barrier
+// (scale_from_hx).  Both roles meet at the same workgroup barriers: one at the head of every hidden layer, one after the second
+// slab of it (between the reader's load of h and the writer's next store), one before the last layer.
+template <int NSLAB, int WT, bool USE_MFMA, bool TANGENT = (NSLAB == 6), bool SECOND = false, int TOFF = 0, int PAIR = 0>
 struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
     using TripleHolder<SECOND && NSLAB <= 10>::tri;
-    static_assert(!TANGENT || (NSLAB >= 2 && NSLAB <= 6 && TOFF + NSLAB - 1 <= 5), "tangent mode = value + a range of the 5 input tangents");
-    static constexpr int kTangents = TANGENT ? NSLAB - 1 : 0;
+    static constexpr bool kNoValue = PAIR == 2;  // every slab is a tangent slab
+    static constexpr int kFirstTangent = kNoValue ? 0 : 1;  // slab index of tangent TOFF
+    static_assert(PAIR == 0 || (TANGENT && USE_MFMA && NSLAB == 3), "wave-pair roles: three slabs each, matrix-core flavour");
+    static_assert(!TANGENT || (NSLAB >= 2 && NSLAB <= 6 && TOFF + NSLAB - kFirstTangent <= 5), "tangent mode = value + a range of the 5 input tangents");
+    static constexpr int kTangents = TANGENT ? NSLAB - kFirstTangent : 0;
     // second-order mode over K inputs (a triple (p, q, r) set with set_triple(), NSLAB = 10; or all five, NSLAB = 21):
     // slab 0 value; 1..K d/dz_i; K+1..2K d2/dz_i2; then d2/dz_i dz_j for the pairs i < j in lexicographic order
     // (K = 3: 7-9 = pq, pr, qr).  NSLAB = 1 + K + K (K + 1) / 2.
@@ -136,6 +144,7 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
     }
     AC_DI int input_of(int i) const { if constexpr (NSLAB <= 10) return tri(i); else return i; }
     static constexpr bool kTangent = TANGENT;
+    static constexpr int kWT = WT;
     static constexpr bool kDeriv = TANGENT || SECOND;  // slabs > 0 are derivative slabs (no bias, chain-rule epilogue)
     // The last layer (width -> 6) of the sensitivity engines runs on the vector ALUs (last_valu below): as an MFMA tile it uses
     // 6 of 16 output rows.  Such engines take the handle's `plan_sens`, whose last-layer block holds [bias][wlt] only.
@@ -153,6 +162,7 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
     int ring_pos;  // number of streamed layers consumed so far (slot = ring_pos & 1)
     int snext;     // position in plan.streamed[] of the next layer to fetch (wraps: the sequence is cyclic)
     Stamper st;    // diagnostic flavor only (empty otherwise)
+    f32x4* hx = nullptr;  // PAIR: this pair's [WT][64 lanes] float4 exchange of the value activations
     // Spread mode (the six-slab sensitivity engine at width 128 with two-tile chunks: 24 chunks per hidden layer): the next
     // streamed layer's LDS-DMA is issued one 1-KiB piece per chunk of the current layer's matrix stream instead of as a burst
     // of 17 pieces behind the barrier — the burst delayed the first blocks' ds_reads (+0.4 % on the headline; with four-tile
@@ -200,7 +210,9 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
         const bool act = ACT < 0 ? act_flag != 0 : ACT != 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (s == 0 || !kDeriv) {
+            if constexpr (kNoValue) {
+                a[s][nt][r] = o[nt][r];  // W t; act'(h) follows in scale_from_hx() once the partner wave has published h
+            } else if (s == 0 || !kDeriv) {
                 a[s][nt][r] = act ? act_tanh(o[nt][r]) : o[nt][r];
             } else if (!SECOND || s <= kFirstOrder) {
                 const float h = a[0][nt][r];  // already the NEW value activation
@@ -239,11 +251,7 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
         f32x4 acc[CNT];
 #pragma unroll
         for (int i = 0; i < CNT; ++i) {
-#ifdef AC_BIAS_AT_HEAD
-            if (s == 0 || !kDeriv) acc[i] = bias4[(nc + i) * 4 + g];
-#else
-            if (s == 0 || !kDeriv) acc[i] = bcur[i];  // a value slab starts from the bias (fetched during the previous chunk)
-#endif
+            if ((s == 0 && !kNoValue) || !kDeriv) acc[i] = bcur[i];  // a value slab starts from the bias (fetched during the previous chunk)
             else acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         f32x4 wnext[CNT];
@@ -266,7 +274,7 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
                 for (int i = 0; i < CNT; ++i) wnext[i] = wf[((nnc + i) * KT + nkt) * 64];
                 // ... and, behind the last block, the bias the next chunk's accumulators start from (read at the head of the
                 // chunk it was one exposed LDS latency per chunk of every value slab: 4 x ~130 cycles per hidden layer)
-                if (last && (kDeriv ? (s == 0 && nc + CNT < NT) : (nc + CNT < NT || s + 1 < NSLAB))) {
+                if (last && !kNoValue && (kDeriv ? (s == 0 && nc + CNT < NT) : (nc + CNT < NT || s + 1 < NSLAB))) {
 #pragma unroll
                     for (int i = 0; i < CNT; ++i) bcur[i] = bias4[(nnc + i) * 4 + g];
                 }
@@ -371,6 +379,17 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
                 gemm_chunk<C, KT, NT, ACT>(wf, bias4, s, nc, o[s & 1], a[s], o[(s + 1) & 1], act, wcur, bcur, more);
             }
             if (KT == WT && NT == WT) { if (s == 0) AC_MARK(st, 9); else if (s == 1) AC_MARK(st, 10); else AC_MARK(st, 11); }
+            if constexpr (PAIR != 0 && KT == WT && NT == WT) {
+                if (s == 1) {
+                    // the partner has read the previous layer's h by now (it did so before its first slab); this layer's
+                    // value epilogue ran inside slab 1's first block, so a[0] is h of THIS layer
+                    __syncthreads();
+                    if constexpr (PAIR == 1) {
+#pragma unroll
+                        for (int nt = 0; nt < WT; ++nt) hx[nt * 64 + lane] = f32x4{a[0][nt][0], a[0][nt][1], a[0][nt][2], a[0][nt][3]};
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) epilogue_tile<NT, ACT>(NSLAB - 1, nt, o[(NSLAB - 1) & 1], act);
@@ -380,14 +399,29 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
     // slabs of the first layer are just columns of W0 scaled by act'(h) — W0[n][j] (1 - h_n^2) — so they are read
     // from a transposed copy of W0 the host appends to the block, with no MFMA at all (saves 5/6 of this layer's
     // matrix work, 3 % of a stage).
+    // PAIR == 2: act'(h) of the hidden layer just finished, h from the partner wave (published before the barrier the caller
+    // has just passed), on this wave's three unscaled slabs — the same product o * (1 - h^2) the one-wave engine forms.
+    AC_DI void scale_from_hx() {
+#pragma unroll
+        for (int nt = 0; nt < WT; ++nt) {
+            const f32x4 h = hx[nt * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sp = fmaf(-h[r], h[r], 1.0f);
+#pragma unroll
+                for (int sl = 0; sl < NSLAB; ++sl) a[sl][nt][r] = a[sl][nt][r] * sp;
+            }
+        }
+    }
+
     // The first layer of the sensitivity engines on the vector ALUs as well: the tangent slabs already read the five columns of
     // W0 (transposed copy, see layer_first), so the value pre-activation is five more packed FMAs on the same registers
     // instead of a padded k-tile on the matrix core and a trip through the accumulators.  Four tiles at a time: eight
     // independent chains.  Products enter in the matrix form's order (z0, z4, z1, z2, z3).
     AC_DI void first_valu(const char* wl, const float z[5]) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x4* bias4 = reinterpret_cast<const f32x4*>(wl + WT * 1024);
-        const f32x4* w0t = reinterpret_cast<const f32x4*>(wl + WT * 1024 + 1024);  // [5][16*WT] floats
+        const f32x4* bias4 = reinterpret_cast<const f32x4*>(wl);          // plan_sens: the block is [bias 1 KiB][W0 transposed]
+        const f32x4* w0t = reinterpret_cast<const f32x4*>(wl + 1024);     // [5][16*WT] floats
         const f32x2 z01 = {z[0], z[1]}, z23 = {z[2], z[3]}, z4x = {z[4], 0.f};
         constexpr int TB = WT < 4 ? WT : 4;
 #pragma unroll
@@ -421,10 +455,10 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float h = act_tanh(pre[i][r >> 1][r & 1]);
-                    a[0][n0 + i][r] = h;
+                    if constexpr (!kNoValue) a[0][n0 + i][r] = h;
                     const float sp = fmaf(-h, h, 1.0f);
 #pragma unroll
-                    for (int j = 0; j < kTangents; ++j) a[1 + j][n0 + i][r] = w[i][TOFF + j][r] * sp;
+                    for (int j = 0; j < kTangents; ++j) a[kFirstTangent + j][n0 + i][r] = w[i][TOFF + j][r] * sp;
                 }
         }
     }
@@ -597,10 +631,12 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
                 if (sl >= NSLAB) continue;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
-                    if (sl == 0) {
+                    if (sl == 0 && !kNoValue) {
                         const float pre = p[i][k] + bias[k];
                         y[k] = act ? act_tanh(pre) : pre;
                         sp[k] = act ? fmaf(-y[k], y[k], 1.0f) : 1.0f;
+                    } else if constexpr (PAIR != 0) {
+                        J[k][sl - kFirstTangent] = p[i][k];  // unscaled: the pair applies act'(y) after its exchange (MlpPairCoeffs)
                     } else {
                         J[k][sl - 1] = sp[k] * p[i][k];
                     }
@@ -635,6 +671,25 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
     // when layers are streamed, workgroup-collective (one barrier per streamed layer).
     template <int JC> AC_DI void forward(const float z[5], float y[6], float (*J)[JC]) {
         static_assert(!kDeriv || JC >= NSLAB - 1, "J holds one column per derivative slab");
+        if constexpr (PAIR != 0) {
+            // wave-pair roles (>= 2 layers: the dispatcher keeps single-layer nets off the pair kernel).  y is this role's only
+            // for PAIR == 1; J holds this role's UNSCALED last-layer columns.
+            const int Lp = plan.n_layers;
+            first_valu(acquire(0), z);
+#pragma nounroll
+            for (int l = 1; l < Lp - 1; ++l) {
+                const char* wl = acquire(l);
+                if (plan.lds_off[l] >= 0) __syncthreads();  // a streamed layer's acquire() has just passed one
+                if constexpr (kNoValue) { if (l > 1) scale_from_hx(); }  // (layer 0's act' this wave formed itself)
+                layer<WT, WT, 1>(wl, 1);
+            }
+            if (Lp > 2) {
+                __syncthreads();
+                if constexpr (kNoValue) scale_from_hx();
+            }
+            last_valu<JC>(acquire(Lp - 1), plan.act[Lp - 1], y, J);
+            return;
+        }
         const int col = lane & 15;
         if constexpr (!kDeriv && NSLAB > 1) {
             // multi-value mode: lane = unit.  Slab s needs z of unit 16 s + col in rows 0..4 (row k on lane group k>>2).
@@ -1029,17 +1084,17 @@ template <class Engine> struct MlpCoeffs {
 };
 
 
-// Provider for a wave PAIR that splits the five input tangents (k_nn_step_sens_pair): this wave's engine delivers y and
-// the Jacobian columns TOFF .. TOFF + Engine::kTangents - 1; the pair completes J through a double-buffered LDS
-// exchange (one workgroup barrier per network evaluation; every wave of the workgroup runs the same sequence).
+// Provider for a wave PAIR that splits the six slabs (k_nn_step_sens_pair): this wave's engine delivers the unscaled
+// last-layer columns TOFF .. TOFF + Engine::kTangents - 1 of the Jacobian (and, role 1, y); the pair completes y and J through
+// one LDS exchange per network evaluation (`xch`: [16 units][36] floats of this pair; single-buffered — the barriers of the
+// next evaluation's hidden layers lie between these reads and the next writes) and applies act'(y) of the last layer.
 template <class Engine, int TOFF> struct MlpPairCoeffs {
     static constexpr int kModel = AC_MODEL_NN;
     Engine& eng;
-    float* xch;  // [2 parities][16 units][30] floats of this pair
-    int parity;
+    float* xch;
     float y[6];
     float J[6][5];
-    AC_DI MlpPairCoeffs(Engine& e, float* exchange) : eng(e), xch(exchange), parity(0) {}
+    AC_DI MlpPairCoeffs(Engine& e, float* exchange) : eng(e), xch(exchange) {}
 
     template <class T> AC_DI void prefetch(const DevParams& P, const T x[13], const float uv[7]) {
         float xf[13];
@@ -1051,21 +1106,26 @@ template <class Engine, int TOFF> struct MlpPairCoeffs {
         float z[5];
 #pragma unroll
         for (int j = 0; j < 5; ++j) z[j] = (in[j] - P.mlp_in_mean[j]) / P.mlp_in_std[j];
-        float Jl[6][5];
-        eng.forward(z, y, Jl);
-        float* buf = xch + parity * (16 * 30) + (eng.lane & 15) * 30;
+        float yl[6], Jl[6][5];
+        eng.forward(z, yl, Jl);
+        float* buf = xch + (eng.lane & 15) * 36;
         if (eng.g == 0) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k)
+            for (int k = 0; k < 6; ++k) {
+                if constexpr (!Engine::kNoValue) buf[k] = yl[k];
 #pragma unroll
-                for (int j = 0; j < Engine::kTangents; ++j) buf[k * 5 + TOFF + j] = Jl[k][j];
+                for (int j = 0; j < Engine::kTangents; ++j) buf[6 + k * 5 + TOFF + j] = Jl[k][j];
+            }
         }
         __syncthreads();
+        const int act = eng.plan.act[eng.plan.n_layers - 1];
 #pragma unroll
-        for (int k = 0; k < 6; ++k)
+        for (int k = 0; k < 6; ++k) {
+            y[k] = buf[k];
+            const float sp = act ? fmaf(-y[k], y[k], 1.0f) : 1.0f;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) J[k][j] = buf[k * 5 + j];
-        parity ^= 1;
+            for (int j = 0; j < 5; ++j) J[k][j] = sp * buf[6 + k * 5 + j];
+        }
     }
 
     AC_DI void operator()(const DevParams& P, const AeroPre<float>& a, const float x[13], const float u[7],

@@ -418,10 +418,14 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
         return AC_OK;
     };
     { const int rc = plan_lds(pl); if (rc != AC_OK) return rc; }
-    // plan_sens: the last layer's LDS copy is [bias 1 KiB][wlt] (the blob keeps the MFMA fragments in front of them)
+    // plan_sens: the first and last layers run on the vector ALUs there (MlpEngine::first_valu / last_valu), so their LDS
+    // copies leave the MFMA fragments out: [bias 1 KiB][W0 transposed] and [bias 1 KiB][wlt] (the blob keeps the fragments
+    // in front of them for the other kernels)
     MlpPlan ps = pl;
     if (n_layers > 1) {
         const int last = n_layers - 1;
+        ps.g_off[0] = pl.g_off[0] + pl.NT[0] * pl.KT[0] * 256;
+        ps.bytes[0] = pl.bytes[0] - pl.NT[0] * pl.KT[0] * 1024;
         ps.g_off[last] = pl.g_off[last] + pl.NT[last] * pl.KT[last] * 256;
         ps.bytes[last] = 1024 + wlt_bytes;
         const int rc = plan_lds(ps);
@@ -747,7 +751,9 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
         const long cus = h->num_cus > 0 ? h->num_cus : 256;
         const long per_round = 64 * cus;
         long n_main = n, n_pair = 0;
-        if (h->use_mfma && !h->no_pair) {
+        // (the pair kernel wants >= 1 hidden layer: its no-value role forms the first layer's act' itself, and the barriers of
+        // the hidden layers separate the reads of one evaluation's output exchange from the next one's writes)
+        if (h->use_mfma && !h->no_pair && h->plan.n_layers >= 3) {
             const long rem = n % per_round;
             if (rem > 0 && rem <= 32 * cus) { n_main = n - rem; n_pair = rem; }
         }
@@ -766,7 +772,7 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
         }
         if (n_pair > 0) {
             const int grid_p = (int)((n_pair + 31) / 32);
-            const int lds_p = h->plan_sens.lds_total + 2 * 2 * 16 * 30 * (int)sizeof(float);  // + the pairs' Jacobian exchange
+            const int lds_p = h->plan_sens.lds_total + 2 * h->wt * 1024 + 2 * 16 * 36 * (int)sizeof(float);  // + the pairs' activation and output exchanges
             bool launched = false;
 #define AC_PAIR_CASE(WT_)                                                                                              \
             if (h->wt == WT_) {                                                                                        \
