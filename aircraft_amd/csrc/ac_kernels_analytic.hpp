@@ -23,6 +23,7 @@ struct UnitAddr {
     AC_DI UnitAddr late() const {
         UnitAddr u = *this;
         asm volatile("" : "+v"(u.q), "+v"(u.r));
+        asm volatile("" : "+s"(u.blk));  // (wave-uniform: a kernel argument) — its row multiples r * blk are not hoisted either
         return u;
     }
 };

@@ -65,6 +65,7 @@ struct ac_handle {
     int device;
     int num_cus;
     bool no_pair;  // AIRCRAFT_HIP_NO_PAIR=1 (measurement aid): never route a remainder to k_nn_step_sens_pair
+    bool all_pair; // AIRCRAFT_HIP_ALL_PAIR=1 (measurement aid): every unit through k_nn_step_sens_pair
     bool has_linear, has_poly, has_mlp;
     MlpPlan plan;
     MlpPlan plan_sens;  // the MFMA sensitivity engines' plan: last layer = [bias][wlt] for MlpEngine::last_valu (ac_set_mlp)
@@ -230,6 +231,8 @@ int ac_create(const ac_params* params, ac_handle** out) {
     {
         const char* e = getenv("AIRCRAFT_HIP_NO_PAIR");
         h->no_pair = e && e[0] == '1';
+        const char* ea = getenv("AIRCRAFT_HIP_ALL_PAIR");
+        h->all_pair = ea && ea[0] == '1';
 #ifdef AC_STAMPS
         h->no_pair = true;  // the diagnostic flavor passes its stamp buffer through `c`; only k_nn_step_sens knows that
 #endif
@@ -756,6 +759,7 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
         if (h->use_mfma && !h->no_pair && h->plan.n_layers >= 3) {
             const long rem = n % per_round;
             if (rem > 0 && rem <= 32 * cus) { n_main = n - rem; n_pair = rem; }
+            if (h->all_pair) { n_main = 0; n_pair = n; }
         }
         if (n_main > 0) {
             const int grid = (int)((n_main + 63) / 64);

@@ -3,6 +3,7 @@
 set -e
 export TMPDIR=/tmp
 rm -f gpurun_out/parity_report.jsonl
+rm -rf gpurun_out/r2_prof_final gpurun_out/r2_pmc_final gpurun_out/r2_pmc_cfg2 gpurun_out/r2_prof_cfg2_256 gpurun_out/r2_prof_cfg2_4096
 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > gpurun_out/r2_pytest_gpu_final.log 2>&1 || true
 tail -3 gpurun_out/r2_pytest_gpu_final.log
 python bench.py > gpurun_out/r2_bench_final.json 2> gpurun_out/r2_bench_final.err
@@ -13,6 +14,10 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU 
   tag=$(echo $grp | tr ' ' '_' | cut -c1-30)
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/r2_pmc_final/$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/r2_pmc_final_$tag.json 2> gpurun_out/r2_pmc_final_$tag.err || echo "pass $tag failed"
 done
+python tools/pmc_traffic.py || true
+# the headline line again, now carrying this build's measured traffic (bench.py reads profiles/r02_pmc_traffic.json)
+python bench.py > gpurun_out/r2_bench_final.json 2> gpurun_out/r2_bench_final.err
+cat gpurun_out/r2_bench_final.json
 # the cfg2 "MFMA off" kernel (k_nn_step_sens_tiled): kernel stats + counters at B=256 (cfg2) and B=4096
 for B in 256 4096; do
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2_prof_cfg2_$B -- python3 bench.py --no-mfma --hidden 64,64,64 --batch $B --steps 10 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/r2_prof_cfg2_$B.json 2> gpurun_out/r2_prof_cfg2_$B.err || true
