@@ -50,3 +50,5 @@ python tools/bench_modes.py > gpurun_out/r2_bench_modes.jsonl 2> gpurun_out/r2_b
 cat gpurun_out/r2_bench_modes.jsonl
 python tools/bench_hess.py > gpurun_out/r2_bench_hess.txt 2>&1 || true
 cat gpurun_out/r2_bench_hess.txt
+# phase stamps of the headline kernel (diagnostic flavour: python aircraft_amd/build.py --diag before the call)
+if [ -f aircraft_amd/libaircraft_hip_diag.so ]; then python tools/diag_stamps.py > gpurun_out/r2_stamps_final.txt 2>&1 || true; cat gpurun_out/r2_stamps_final.txt; fi
