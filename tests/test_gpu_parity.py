@@ -286,6 +286,34 @@ def test_activation_free_layers_are_folded(gpu, act):
     assert eh.max() < 2e-3, (int(eh.argmax()), float(eh.max()))
 
 
+@pytest.mark.parametrize("hidden", [(128,), (128, 128), (100, 128), (128, 128, 128)])
+def test_wide_nets_resident_and_streamed(gpu, hidden):
+    """Width-128 nets (eight register tiles per slab) whose hidden layers all FIT the LDS (one or two layers: no ring, the
+    six-slab engine's LDS-DMA issue points re-copy a resident piece onto itself; the wave pair meets at explicit barriers
+    instead of the ring's) next to the smallest net that streams (three): step + sensitivities against the oracle, every
+    unit on its own, through the one-wave kernel and — 100 units: less than half a round — the wave-pair kernel, and the
+    two bit-identical on the units they share."""
+    import torch
+
+    ac = make_aircraft("nn", hidden=hidden, normalise=True)
+    orc = make_oracle(ac)
+    n_big = 16384 + 100
+    X, U = synthetic_units(n_big, seed=41, flaps=True)
+    small = ac.step_sens(dev(X[:, :100], gpu), dev(U[:, :100], gpu), 0.01)
+    name = ac.last_launch()[0]
+    # (a net without a hidden layer stays on the one-wave kernel: the pair's exchange relies on the hidden layers' barriers)
+    assert name == ("k_nn_step_sens_pair" if len(hidden) >= 2 else "k_nn_step_sens"), name
+    Xr, Ar, Br, cr = orc.step_sens(X[:, :100], U[:, :100], 0.01)
+    assert block_rel_err(small[0].cpu().numpy(), Xr) < STATE_TOL
+    assert_sens(f"step_sens_wide{hidden}", {"A": small[1], "B": small[2], "c": small[3]}, {"A": Ar, "B": Br, "c": cr})
+    big = ac.step_sens(dev(X, gpu), dev(U, gpu), 0.01)  # one whole round in the one-wave kernel + the pair remainder
+    for got, want in zip(small, big):
+        assert torch.equal(got, want[..., :100])
+    fd = ac.state_derivative_sens(dev(X[:, :100], gpu), dev(U[:, :100], gpu))
+    xd, Fx, Fu = orc.state_derivative_sens(X[:, :100], U[:, :100])
+    assert float(unit_max_rel(fd[1].cpu().numpy(), Fx).max()) < 1e-4
+
+
 def test_mfma_and_valu_paths_agree(gpu):
     """v_mfma_f32_16x16x4_f32 is an exact k-ordered fp32 fma chain; the VALU cross-lane path does the same
     contraction, so the two must agree to the last bit or two."""
