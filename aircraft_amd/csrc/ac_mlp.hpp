@@ -922,7 +922,9 @@ struct MlpEngineCoopReg {
     float a[WT][4];
     f32x4 w0[T], b0[T];            // first layer: one k-tile
     f32x4 wh[NH][T][WT], bh[NH][T];
-    f32x4 wl[WT], bl;              // last layer: tile 0, used by wave 0
+    static constexpr int NP = WT >= kWaves ? kWaves : WT;  // waves sharing the last layer's contraction
+    static constexpr int KW = WT / NP;                     // k-tiles of the last layer per participating wave
+    f32x4 wl[KW], bl;              // last layer (one output tile): this wave's k-tiles; the bias enters through wave 0
     const MlpPlan& plan;
     f32x4* xbuf;                   // [2][WT tiles][64 lanes]
     int lane, g, wave, t0, buf;
@@ -949,7 +951,7 @@ struct MlpEngineCoopReg {
         }
         const f32x4* gL = reinterpret_cast<const f32x4*>(blob + pl.g_off[1 + NH]);
 #pragma unroll
-        for (int kt = 0; kt < WT; ++kt) wl[kt] = gL[kt * 64 + lane];
+        for (int i = 0; i < KW; ++i) wl[i] = gL[((wave < NP ? wave : 0) * KW + i) * 64 + lane];
         bl = gL[WT * 64 + g];
     }
     AC_DI void load_weights() {}
@@ -1014,16 +1016,33 @@ struct MlpEngineCoopReg {
             }
             exchange<WT>();
         }
-        // last layer: one output tile, wave 0
-        if (wave == 0) {
-            f32x4 acc = bl;
+        // last layer: ONE output tile, whose 4 WT dependent MFMAs would be a latency chain on one wave while three wait: the
+        // contraction is split over the waves' k-tiles instead, the partial tiles are summed (fixed order) by every wave
+        if (wave < NP) {
+            f32x4 acc = wave == 0 ? bl : f32x4{0.f, 0.f, 0.f, 0.f};
+            // (a wave-uniform branch per participant: the activation registers are indexed statically)
 #pragma unroll
-            for (int kt = 0; kt < WT; ++kt)
+            for (int w = 0; w < NP; ++w) {
+                if (wave == w) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc = mma_16x16x4<USE_MFMA>(wl[kt][r], a[kt][r], acc);
-            xbuf[buf * (WT * 64) + lane] = activate(acc, plan.act[1 + NH]);
+                    for (int i = 0; i < KW; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc = mma_16x16x4<USE_MFMA>(wl[i][r], a[w * KW + i][r], acc);
+                }
+            }
+            xbuf[buf * (WT * 64) + wave * 64 + lane] = acc;
         }
-        exchange<1>();
+        __syncthreads();
+        {
+            const f32x4* src = xbuf + buf * (WT * 64);
+            f32x4 sum = src[lane];
+#pragma unroll
+            for (int w = 1; w < NP; ++w) sum += src[w * 64 + lane];
+            const f32x4 h = activate(sum, plan.act[1 + NH]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[0][r] = h[r];
+            buf ^= 1;
+        }
         const int col = lane & 15;
 #pragma unroll
         for (int k = 0; k < 6; ++k) y[k] = __shfl(a[0][k & 3], col + 16 * (k >> 2), 64);
