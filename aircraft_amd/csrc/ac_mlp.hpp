@@ -561,17 +561,29 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
         const f32x4* wv = reinterpret_cast<const f32x4*>(wl + 1024) + g * 6;
         const float* bias = reinterpret_cast<const float*>(wl);
         float sp[6];
-        // two slabs at a time, even and odd rows on accumulators of their own: twelve independent chains (a dependent
-        // v_pk_fma_f32 issues ~38 cycles after its producer, profiles/r02_micro_pkfma_banks.txt), and a slab's 4 WT activation
-        // registers are dead once its group is done (all six slabs at once: 100 B of scratch per lane)
+#ifndef AC_LV_GROUP
+#define AC_LV_GROUP 6
+#endif
+#ifndef AC_LV_PARITY
+#define AC_LV_PARITY 1
+#endif
+        // kGroup slabs at a time (the weight image is re-read per group), kPar accumulators per (slab, output pair) — 2 = even
+        // and odd rows apart.  All slabs in one pass, one accumulator each: 18 independent chains in the six-slab engine (a
+        // dependent v_pk_fma_f32 issues ~38 cycles after its producer, profiles/r02_micro_pkfma_banks.txt: ten chains cover
+        // it) and one read of the weight image instead of three — the four waves of the workgroup read it in the same phase,
+        // and it was the LDS, not the vector ALU, that set this layer's time: same-box A/B 3.849-3.862 ms against 3.875-3.884
+        // for pairs of slabs with split rows, 3.865-3.872 for triples.  (36 accumulator registers next to the 192 activation
+        // registers cost 100 B of scratch while the kernel still spilled elsewhere; none now.)
+        constexpr int kGroup = NSLAB < AC_LV_GROUP ? NSLAB : AC_LV_GROUP, kPar = AC_LV_PARITY;
 #pragma unroll
-        for (int s0 = 0; s0 < NSLAB; s0 += 2) {
-            constexpr int kGroup = 2;
-            f32x2 acc[kGroup][3][2];
+        for (int s0 = 0; s0 < NSLAB; s0 += kGroup) {
+            f32x2 acc[kGroup][3][kPar];
 #pragma unroll
             for (int i = 0; i < kGroup; ++i)
 #pragma unroll
-                for (int kp = 0; kp < 3; ++kp) acc[i][kp][0] = acc[i][kp][1] = f32x2{0.f, 0.f};
+                for (int kp = 0; kp < 3; ++kp)
+#pragma unroll
+                    for (int q = 0; q < kPar; ++q) acc[i][kp][q] = f32x2{0.f, 0.f};
             f32x4 w[2][6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) w[0][i] = wv[i];
@@ -593,37 +605,34 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
                         for (int kp = 0; kp < 3; ++kp) {
                             const f32x4 wq = wc[2 * kp + (r >> 1)];
                             const f32x2 wp = (r & 1) ? f32x2{wq[2], wq[3]} : f32x2{wq[0], wq[1]};
-                            if (r & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[i][kp][1]) : "v"(ap), "v"(wp));
-                            else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[i][kp][0]) : "v"(ap), "v"(wp));
+                            f32x2& dst = acc[i][kp][kPar == 2 ? (r & 1) : 0];
+                            if (r & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(dst) : "v"(ap), "v"(wp));
+                            else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(dst) : "v"(ap), "v"(wp));
                         }
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            float p[kGroup][6];
+            // the group's partial sums, flat [slab][output]; unit totals four at a time
+            constexpr int kVals = 6 * kGroup, kQuads = (kVals + 3) / 4;
+            float p[kQuads * 4];
+#pragma unroll
+            for (int i = 0; i < kQuads * 4; ++i) p[i] = 0.f;
 #pragma unroll
             for (int i = 0; i < kGroup; ++i)
 #pragma unroll
                 for (int kp = 0; kp < 3; ++kp) {
-                    const f32x2 sum = acc[i][kp][0] + acc[i][kp][1];
-                    p[i][2 * kp] = sum[0]; p[i][2 * kp + 1] = sum[1];
+                    f32x2 sum = acc[i][kp][0];
+                    if constexpr (kPar == 2) sum += acc[i][kp][1];
+                    p[i * 6 + 2 * kp] = sum[0]; p[i * 6 + 2 * kp + 1] = sum[1];
                 }
-            const bool two = s0 + 1 < NSLAB;
-            {
-                float q[4] = {p[0][0], p[0][1], p[0][2], p[0][3]};
-                unit_totals4(q);
+            const int live = (NSLAB - s0 < kGroup ? NSLAB - s0 : kGroup) * 6;  // compile-time after unrolling
 #pragma unroll
-                for (int k = 0; k < 4; ++k) p[0][k] = q[k];
-            }
-            if (two) {
-                float q[4] = {p[1][0], p[1][1], p[1][2], p[1][3]};
-                unit_totals4(q);
+            for (int q = 0; q < kQuads; ++q) {
+                if (4 * q >= live) continue;
+                float v[4] = {p[4 * q], p[4 * q + 1], p[4 * q + 2], p[4 * q + 3]};
+                unit_totals4(v);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) p[1][k] = q[k];
-            }
-            {
-                float q[4] = {p[0][4], p[0][5], two ? p[1][4] : 0.f, two ? p[1][5] : 0.f};
-                unit_totals4(q);
-                p[0][4] = q[0]; p[0][5] = q[1]; p[1][4] = q[2]; p[1][5] = q[3];
+                for (int e = 0; e < 4; ++e) p[4 * q + e] = v[e];
             }
 #pragma unroll
             for (int i = 0; i < kGroup; ++i) {
@@ -631,14 +640,15 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
                 if (sl >= NSLAB) continue;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
+                    const float tot = p[i * 6 + k];
                     if (sl == 0 && !kNoValue) {
-                        const float pre = p[i][k] + bias[k];
+                        const float pre = tot + bias[k];
                         y[k] = act ? act_tanh(pre) : pre;
                         sp[k] = act ? fmaf(-y[k], y[k], 1.0f) : 1.0f;
                     } else if constexpr (PAIR != 0) {
-                        J[k][sl - kFirstTangent] = p[i][k];  // unscaled: the pair applies act'(y) after its exchange (MlpPairCoeffs)
+                        J[k][sl - kFirstTangent] = tot;  // unscaled: the pair applies act'(y) after its exchange (MlpPairCoeffs)
                     } else {
-                        J[k][sl - 1] = sp[k] * p[i][k];
+                        J[k][sl - 1] = sp[k] * tot;
                     }
                 }
             }
