@@ -12,7 +12,7 @@ from tests.helpers import make_aircraft
 
 dev = torch.device("cuda", 0)
 
-def timeit(fn, iters=10, warm=2):
+def timeit(fn, iters=30, warm=5):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
