@@ -115,19 +115,24 @@ AC_DI void sens_pair_body(const DevParams& P, const MlpPlan& plan, const float* 
     load_rows<13>(X, ua, xv);
     load_rows<7>(U, ua, uv);
     const float hv = dt_per_unit ? dt_per_unit[unit] : dt;
-    Dual<4> x[13];
+    // The sixteen tangent directions of a unit are split over the pair as well: eight lanes per unit (four in each wave), two
+    // directions per lane — each wave runs the dual RK4 arithmetic on Dual<2> instead of both on Dual<4> (the value parts are
+    // computed twice, the derivative parts once).  Lane-local for one RK4 sub-step; the dispatcher keeps sub-stepped updates
+    // (whose composition shuffles across the lanes of a unit inside one wave) on the one-wave kernel.
+    (void)store;
+    const int g8 = 4 * (Engine::kNoValue ? 1 : 0) + g;
+    Dual<2> x[13];
     MlpPairCoeffs<Engine, TOFF> coeffs(eng, xch);
-    const bool out = live && store;
-    sens_update<4>(P, coeffs, g, col, ua, xv, uv, hv, x, A, Bm, c, out);
+    sens_update<2>(P, coeffs, g8, col, ua, xv, uv, hv, x, A, Bm, c, live);
     eng.drain();
-    if (out) {
+    if (live) {
         const UnitAddr uo = ua.late();
-        if (g == 0) {
+        if (g8 == 0) {
             float* p = Xn + uo.off(13);
 #pragma unroll
             for (int i = 0; i < 13; ++i) p[(long)i * blk] = x[i].v;
         }
-        SensIO::store(g, uo, x, A, Bm, c, true);
+        SensIOT<2>::store(g8, uo, x, A, Bm, c, true);
     }
 }
 

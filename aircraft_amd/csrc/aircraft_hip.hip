@@ -756,7 +756,7 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
         long n_main = n, n_pair = 0;
         // (the pair kernel wants >= 1 hidden layer: its no-value role forms the first layer's act' itself, and the barriers of
         // the hidden layers separate the reads of one evaluation's output exchange from the next one's writes)
-        if (h->use_mfma && !h->no_pair && h->plan.n_layers >= 3) {
+        if (h->use_mfma && !h->no_pair && h->plan.n_layers >= 3 && h->dp.p.substeps <= 1) {  // (sub-stepped updates: one-wave kernel)
             const long rem = n % per_round;
             if (rem > 0 && rem <= 32 * cus) { n_main = n - rem; n_pair = rem; }
             if (h->all_pair) { n_main = 0; n_pair = n; }
