@@ -4,7 +4,8 @@ import numpy as np, torch
 from tests.helpers import block_rel_err, f32_exact, make_aircraft, make_oracle, oracle_step_hessian, rel_fro, synthetic_units
 from tests.test_gpu_fuzz import MODELS, dev
 gpu = torch.device("cuda", 0)
-for seed in (32, 44, 67, 69, 80, 146, 157, 164, 188, 206):
+SEEDS = [int(a) for a in sys.argv[1:]] or [32, 44, 67, 69, 80, 146, 157, 164, 188, 206]
+for seed in SEEDS:
     rng = np.random.default_rng(1000 + seed)
     model, hidden = MODELS[seed % len(MODELS)]
     substeps = int(rng.choice([1, 1, 2, 3])); normalise = bool(rng.integers(2)); stall = bool(rng.integers(2))

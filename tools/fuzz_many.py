@@ -4,7 +4,8 @@ import torch
 from tests.test_gpu_fuzz import test_random_configuration as f
 gpu = torch.device("cuda", 0)
 bad = []
-for seed in range(12, 212):
+lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (12, 212)
+for seed in range(lo, hi):
     try:
         f(gpu, seed)
     except Exception as e:
