@@ -146,9 +146,10 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
     static constexpr bool kTangent = TANGENT;
     static constexpr int kWT = WT;
     static constexpr bool kDeriv = TANGENT || SECOND;  // slabs > 0 are derivative slabs (no bias, chain-rule epilogue)
-    // The last layer (width -> 6) of the sensitivity engines runs on the vector ALUs (last_valu below): as an MFMA tile it uses
-    // 6 of 16 output rows.  Such engines take the handle's `plan_sens`, whose last-layer block holds [bias][wlt] only.
-    static constexpr bool kVLast = TANGENT && USE_MFMA;
+    // The first and last layers (5 -> width, width -> 6) of the matrix-core engines run on the vector ALUs (first_valu / last_valu
+    // below): as MFMA tiles they are mostly padding.  Such engines take the handle's `plan_sens`, whose edge blocks hold
+    // [bias][W0 transposed] and [bias][wlt] only.  (The second-order engines keep the matrix form and `plan`.)
+    static constexpr bool kVLast = USE_MFMA && !SECOND;  // (the value-only engines of the forward kernels as well: *_values below)
 #ifndef AC_CH
 #define AC_CH 4  // the two headline units are built with 2 (build.py UNIT_FLAGS): 84 % less spill, DESIGN.md §6
 #endif
@@ -463,6 +464,133 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
         }
     }
 
+    // The edge layers of the VALUE-ONLY engines (forward kernels: every slab a value slab of its own units, NSLAB = 1 or 4) on
+    // the vector ALUs, as first_valu / last_valu do for the sensitivity engines.  Slab s carries units 16 s + col (NSLAB = 4:
+    // lane = unit, so z comes from lane col + 16 s) or the lane's own unit (NSLAB = 1).
+    AC_DI void first_valu_values(const char* wl, const float z[5]) {
+        static_assert(!kDeriv, "value slabs only");
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x4* bias4 = reinterpret_cast<const f32x4*>(wl);
+        const f32x4* w0t = reinterpret_cast<const f32x4*>(wl + 1024);
+        const int col = lane & 15;
+        f32x2 z01[NSLAB], z23[NSLAB], z4x[NSLAB];
+#pragma unroll
+        for (int sl = 0; sl < NSLAB; ++sl) {
+            float zz[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) zz[k] = NSLAB > 1 ? __shfl(z[k], col + 16 * sl, 64) : z[k];
+            z01[sl] = f32x2{zz[0], zz[1]}; z23[sl] = f32x2{zz[2], zz[3]}; z4x[sl] = f32x2{zz[4], 0.f};
+        }
+        constexpr int TB = WT < 2 ? WT : 2;
+#pragma unroll
+        for (int n0 = 0; n0 < WT; n0 += TB) {
+            f32x4 w[TB][5], b[TB];
+#pragma unroll
+            for (int i = 0; i < TB; ++i) {
+                b[i] = bias4[(n0 + i) * 4 + g];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) w[i][j] = w0t[j * (WT * 4) + 4 * (n0 + i) + g];
+            }
+            f32x2 pre[NSLAB][TB][2];
+#pragma unroll
+            for (int sl = 0; sl < NSLAB; ++sl)
+#pragma unroll
+                for (int i = 0; i < TB; ++i) { pre[sl][i][0] = f32x2{b[i][0], b[i][1]}; pre[sl][i][1] = f32x2{b[i][2], b[i][3]}; }
+#pragma unroll
+            for (int step = 0; step < 5; ++step) {
+                constexpr int order[5] = {0, 4, 1, 2, 3};
+                const int j = order[step];
+#pragma unroll
+                for (int sl = 0; sl < NSLAB; ++sl)
+#pragma unroll
+                    for (int i = 0; i < TB; ++i)
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const f32x2 wp = {w[i][j][2 * hh], w[i][j][2 * hh + 1]};
+                            const f32x2 zp = j < 2 ? z01[sl] : (j < 4 ? z23[sl] : z4x[sl]);
+                            if (j & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(pre[sl][i][hh]) : "v"(wp), "v"(zp));
+                            else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(pre[sl][i][hh]) : "v"(wp), "v"(zp));
+                        }
+            }
+#pragma unroll
+            for (int sl = 0; sl < NSLAB; ++sl)
+#pragma unroll
+                for (int i = 0; i < TB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[sl][n0 + i][r] = act_tanh(pre[sl][i][r >> 1][r & 1]);
+        }
+    }
+
+    AC_DI void last_valu_values(const char* wl, int act, float y[6]) {
+        static_assert(!kDeriv && (NSLAB == 1 || NSLAB == 4), "value slabs only");
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x4* wv = reinterpret_cast<const f32x4*>(wl + 1024) + g * 6;
+        const float* bias = reinterpret_cast<const float*>(wl);
+        constexpr int kPar = 4;  // one accumulator per row r in BOTH engines: the one-slab engine needs the twelve chains, and a
+                                 // unit's result must not depend on which of the two evaluates it (same products, same order)
+        f32x2 acc[NSLAB][3][kPar];
+#pragma unroll
+        for (int sl = 0; sl < NSLAB; ++sl)
+#pragma unroll
+            for (int kp = 0; kp < 3; ++kp)
+#pragma unroll
+                for (int q = 0; q < kPar; ++q) acc[sl][kp][q] = f32x2{0.f, 0.f};
+        f32x4 w[2][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[0][i] = wv[i];
+#pragma unroll
+        for (int t = 0; t < WT; ++t) {
+            if (t + 1 < WT) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) w[(t + 1) & 1][i] = wv[(t + 1) * 24 + i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 (&wc)[6] = w[t & 1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int sl = 0; sl < NSLAB; ++sl) {
+                    const f32x2 ap = {a[sl][t][r & 2], a[sl][t][(r & 2) + 1]};
+#pragma unroll
+                    for (int kp = 0; kp < 3; ++kp) {
+                        const f32x4 wq = wc[2 * kp + (r >> 1)];
+                        const f32x2 wp = (r & 1) ? f32x2{wq[2], wq[3]} : f32x2{wq[0], wq[1]};
+                        f32x2& dst = acc[sl][kp][kPar == 4 ? r : 0];
+                        if (r & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(dst) : "v"(ap), "v"(wp));
+                        else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(dst) : "v"(ap), "v"(wp));
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float p[NSLAB][6];
+#pragma unroll
+        for (int sl = 0; sl < NSLAB; ++sl)
+#pragma unroll
+            for (int kp = 0; kp < 3; ++kp) {
+                f32x2 sum = acc[sl][kp][0];
+                if constexpr (kPar == 4) sum = (sum + acc[sl][kp][1]) + (acc[sl][kp][2] + acc[sl][kp][3]);
+                p[sl][2 * kp] = sum[0]; p[sl][2 * kp + 1] = sum[1];
+            }
+        float tot[6];
+        if constexpr (NSLAB == 4) {
+            // lane (col, g) is unit 16 g + col = slab g: the reduce-scatter alone hands row g the total of slab g
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float v[4] = {p[0][k], p[2][k], p[1][k], p[3][k]};
+                tot[k] = unit_scatter4(v);
+            }
+        } else {
+            float q0[4] = {p[0][0], p[0][1], p[0][2], p[0][3]}, q1[4] = {p[0][4], p[0][5], 0.f, 0.f};
+            unit_totals4(q0); unit_totals4(q1);
+            tot[0] = q0[0]; tot[1] = q0[1]; tot[2] = q0[2]; tot[3] = q0[3]; tot[4] = q1[0]; tot[5] = q1[1];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float pre = tot[k] + bias[k];
+            y[k] = act ? act_tanh(pre) : pre;
+        }
+    }
+
     AC_DI void layer_first(const char* wl) {
         constexpr bool act = true;  // not the last layer (see forward()): always tanh after the host-side fold
         const f32x4* wf = reinterpret_cast<const f32x4*>(wl) + lane;
@@ -530,10 +658,8 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
     // all four, by unit_totals4 above.  wl: the block [bias 1 KiB]
     // [wlt: per (tile t, lane group g) six float4 {W[2kp][n], W[2kp+1][n], W[2kp][n+1], W[2kp+1][n+1]}, n = 16t+4g+2rp, index
     // (t*4+g)*6 + 2 kp + rp] the host packs (ac_set_mlp).  Outputs go straight to y / J: no output tile, no broadcast.
-    // Totals of four per-lane values over the four lanes of a unit (lanes col, col + 16, col + 32, col + 48), handed to all
-    // four: a reduce-scatter by v_permlane32_swap / v_permlane16_swap (two values per swap) and the mirror-image all-gather —
-    // 12 swaps and 3 adds for four values, every total formed once (the four lanes hold the same bits).
-    AC_DI static void unit_totals4(float (&v)[4]) {
+    // The reduce-scatter half on its own: row g of the result carries the total of v[0], v[2], v[1], v[3] for g = 0, 1, 2, 3.
+    AC_DI static float unit_scatter4(const float (&v)[4]) {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         auto sw32 = [](float p, float q, float& lo, float& hi) {
             const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(q), false, false);
@@ -549,7 +675,22 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
         const float w0 = l0 + h0, w1 = l1 + h1;
         float l2, h2;
         sw16(w0, w1, l2, h2);
-        const float u = l2 + h2;   // row 0: total of v0, row 1: v2, row 2: v1, row 3: v3
+        return l2 + h2;
+    }
+    // Totals of four per-lane values over the four lanes of a unit (lanes col, col + 16, col + 32, col + 48), handed to all
+    // four: a reduce-scatter by v_permlane32_swap / v_permlane16_swap (two values per swap) and the mirror-image all-gather —
+    // 12 swaps and 3 adds for four values, every total formed once (the four lanes hold the same bits).
+    AC_DI static void unit_totals4(float (&v)[4]) {
+        const float u = unit_scatter4(v);  // row 0: total of v0, row 1: v2, row 2: v1, row 3: v3
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        auto sw32 = [](float p, float q, float& lo, float& hi) {
+            const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(q), false, false);
+            lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+        };
+        auto sw16 = [](float p, float q, float& lo, float& hi) {
+            const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(q), false, false);
+            lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+        };
         float e, o;
         sw16(u, u, e, o);          // e = rows (0, 0, 2, 2) of u, o = rows (1, 1, 3, 3)
         sw32(e, e, v[0], v[1]);
@@ -748,7 +889,9 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
                 layer<1, 1>(acquire(0), plan.act[0]);
             }
         } else {
-            if constexpr (kVLast) first_valu(acquire(0), z); else layer_first(acquire(0));
+            if constexpr (kVLast && kDeriv) first_valu(acquire(0), z);
+            else if constexpr (kVLast) first_valu_values(acquire(0), z);
+            else layer_first(acquire(0));
             AC_MARK(st, 2);  // [2] first layer
 #pragma nounroll
             for (int l = 1; l < L - 1; ++l) {
@@ -757,7 +900,12 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
                 layer<WT, WT, 1>(wl, 1);  // tanh on every layer but the last: ac_set_mlp folds activation-free layers away
                 AC_MARK(st, 4);  // [4] hidden layer GEMM + epilogues
             }
-            if constexpr (kVLast) {
+            if constexpr (kVLast && !kDeriv) {
+                last_valu_values(acquire(L - 1), plan.act[L - 1], y);
+                AC_MARK(st, 5);
+                AC_MARK(st, 6);
+                return;
+            } else if constexpr (kVLast) {
                 last_valu<JC>(acquire(L - 1), plan.act[L - 1], y, J);
                 AC_MARK(st, 5);  // [5] last layer
                 AC_MARK(st, 6);

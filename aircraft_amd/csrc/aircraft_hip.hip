@@ -185,7 +185,8 @@ void launch_hess(ac_handle* h, hipStream_t st, const float* X, const float* U, f
         launched = true;                                                                             \
     }
 #define AC_NN_CASE(WT_, MF_, KERNEL_EXPR, GRID, BLOCK, ...) AC_NN_CASE_PLAN(h->plan, WT_, MF_, KERNEL_EXPR, GRID, BLOCK, __VA_ARGS__)
-// the six-slab sensitivity kernels: the matrix-core flavour runs its last layer on the vector ALUs and takes plan_sens
+// kernels on MlpEngine (sensitivity and forward): the matrix-core flavour runs its edge layers on the vector ALUs and takes
+// plan_sens; the cross-lane validation flavour keeps plan.  (The second-order and the cooperative rollout engines: plan.)
 #define AC_NN_CASE_SENS(WT_, MF_, KERNEL_EXPR, GRID, BLOCK, ...)                                      \
     if (MF_) { AC_NN_CASE_PLAN(h->plan_sens, WT_, MF_, KERNEL_EXPR, GRID, BLOCK, __VA_ARGS__) }       \
     else { AC_NN_CASE_PLAN(h->plan, WT_, MF_, KERNEL_EXPR, GRID, BLOCK, __VA_ARGS__) }
@@ -546,31 +547,31 @@ static int launch_nn_fwd(ac_handle* h, int op, const float* X, const float* U, f
         const long zero = 0;
 #define AC_FWD4_CASE(WT_)                                                                                        \
         if (h->wt == WT_) {                                                                                      \
-            if (op == OP_DERIV) { AC_NN_CASE(WT_, true, (k_nn_fwd4<WT_, OP_DERIV>), grid4, kBlock, X, U, dt, dtp, n4, blk, out, zero) } \
-            else if (op == OP_STEP) { AC_NN_CASE(WT_, true, (k_nn_fwd4<WT_, OP_STEP>), grid4, kBlock, X, U, dt, dtp, n4, blk, out, zero) } \
-            else { AC_NN_CASE(WT_, true, (k_nn_fwd4<WT_, OP_AERO>), grid4, kBlock, X, U, dt, dtp, n4, blk, out, zero) }    \
+            if (op == OP_DERIV) { AC_NN_CASE_SENS(WT_, true, (k_nn_fwd4<WT_, OP_DERIV>), grid4, kBlock, X, U, dt, dtp, n4, blk, out, zero) } \
+            else if (op == OP_STEP) { AC_NN_CASE_SENS(WT_, true, (k_nn_fwd4<WT_, OP_STEP>), grid4, kBlock, X, U, dt, dtp, n4, blk, out, zero) } \
+            else { AC_NN_CASE_SENS(WT_, true, (k_nn_fwd4<WT_, OP_AERO>), grid4, kBlock, X, U, dt, dtp, n4, blk, out, zero) }    \
         }
         AC_FWD4_CASE(2) AC_FWD4_CASE(4) AC_FWD4_CASE(8)
 #undef AC_FWD4_CASE
         if (!launched) return fail(AC_ERR_UNSUPPORTED, "no kernel instance for this MLP width / flavour");
         note_launch(h, op == OP_DERIV ? "k_nn_fwd4<deriv>" : (op == OP_STEP ? "k_nn_fwd4<step>" : "k_nn_fwd4<aero>"), grid4,
-                    kBlock, h->plan.lds_total);
+                    kBlock, (h->use_mfma ? h->plan_sens : h->plan).lds_total);
         AC_HIP(hipGetLastError());
         if (n4 == n) return AC_OK;
         launched = false;
     }
     const int grid = (int)((n - n4 + 63) / 64);
 #define AC_FWD_OPS(WT_, MF_)                                                                                   \
-    if (op == OP_DERIV) { AC_NN_CASE(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_DERIV>), grid, kBlock, X, U, dt, dtp, n, blk, out, n4) } \
-    else if (op == OP_STEP) { AC_NN_CASE(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_STEP>), grid, kBlock, X, U, dt, dtp, n, blk, out, n4) } \
-    else { AC_NN_CASE(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_AERO>), grid, kBlock, X, U, dt, dtp, n, blk, out, n4) }
+    if (op == OP_DERIV) { AC_NN_CASE_SENS(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_DERIV>), grid, kBlock, X, U, dt, dtp, n, blk, out, n4) } \
+    else if (op == OP_STEP) { AC_NN_CASE_SENS(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_STEP>), grid, kBlock, X, U, dt, dtp, n, blk, out, n4) } \
+    else { AC_NN_CASE_SENS(WT_, MF_, (k_nn_fwd<WT_, MF_, OP_AERO>), grid, kBlock, X, U, dt, dtp, n, blk, out, n4) }
     AC_FWD_OPS(2, true) AC_FWD_OPS(4, true) AC_FWD_OPS(8, true)
     AC_FWD_OPS(2, false) AC_FWD_OPS(4, false) AC_FWD_OPS(8, false)
 #undef AC_FWD_OPS
     if (!launched) return fail(AC_ERR_UNSUPPORTED, "no kernel instance for this MLP width / flavour");
     if (n4 == 0)
         note_launch(h, op == OP_DERIV ? "k_nn_fwd<deriv>" : (op == OP_STEP ? "k_nn_fwd<step>" : "k_nn_fwd<aero>"), grid,
-                    kBlock, h->plan.lds_total);
+                    kBlock, (h->use_mfma ? h->plan_sens : h->plan).lds_total);
     AC_HIP(hipGetLastError());
     return AC_OK;
 }
@@ -703,14 +704,14 @@ int ac_rollout_f32(ac_handle* h, const float* X0, const float* U, float dt, long
             return AC_OK;
         }
         const int grid = (int)((groups + 3) / 4);
-        AC_NN_CASE(2, true, (k_nn_rollout<2, true>), grid, kBlock, X0, U, dt, B, H, Xout)
-        AC_NN_CASE(4, true, (k_nn_rollout<4, true>), grid, kBlock, X0, U, dt, B, H, Xout)
-        AC_NN_CASE(8, true, (k_nn_rollout<8, true>), grid, kBlock, X0, U, dt, B, H, Xout)
-        AC_NN_CASE(2, false, (k_nn_rollout<2, false>), grid, kBlock, X0, U, dt, B, H, Xout)
-        AC_NN_CASE(4, false, (k_nn_rollout<4, false>), grid, kBlock, X0, U, dt, B, H, Xout)
-        AC_NN_CASE(8, false, (k_nn_rollout<8, false>), grid, kBlock, X0, U, dt, B, H, Xout)
+        AC_NN_CASE_SENS(2, true, (k_nn_rollout<2, true>), grid, kBlock, X0, U, dt, B, H, Xout)
+        AC_NN_CASE_SENS(4, true, (k_nn_rollout<4, true>), grid, kBlock, X0, U, dt, B, H, Xout)
+        AC_NN_CASE_SENS(8, true, (k_nn_rollout<8, true>), grid, kBlock, X0, U, dt, B, H, Xout)
+        AC_NN_CASE_SENS(2, false, (k_nn_rollout<2, false>), grid, kBlock, X0, U, dt, B, H, Xout)
+        AC_NN_CASE_SENS(4, false, (k_nn_rollout<4, false>), grid, kBlock, X0, U, dt, B, H, Xout)
+        AC_NN_CASE_SENS(8, false, (k_nn_rollout<8, false>), grid, kBlock, X0, U, dt, B, H, Xout)
         if (!launched) return fail(AC_ERR_UNSUPPORTED, "no kernel instance for this MLP width / flavour");
-        note_launch(h, "k_nn_rollout", grid, kBlock, h->plan.lds_total);
+        note_launch(h, "k_nn_rollout", grid, kBlock, (h->use_mfma ? h->plan_sens : h->plan).lds_total);
         AC_HIP(hipGetLastError());
         return AC_OK;
     }
