@@ -265,6 +265,32 @@ def test_forward_64_units_per_wave_path(gpu, hidden):
     assert block_rel_err(out2[:, idx], orc.state_update(X[:, idx], U[:, idx], f32_exact(dt)[idx])) < 1e-5
 
 
+@pytest.mark.parametrize("hidden", [(128, 128, 128, 128), (64, 64, 64)])
+def test_rollout_one_wave_kernel_for_very_large_batches(gpu, hidden):
+    """B >= 65 536 instances roll out in k_nn_rollout (one wave per 16 instances, the forward engine with its edge layers on
+    the vector ALUs) instead of the cooperative kernels: a sample against the oracle, and the same instances through the
+    cooperative kernel (a smaller batch) to rounding."""
+    import torch
+    from aircraft_amd.synthetic import near_trim_problem
+
+    ac = make_aircraft("nn", hidden=hidden, normalise=True)
+    B, H = 65536 + 48, 3
+    X0s, Us = near_trim_problem(64, H, seed=9)
+    reps = -(-B // 64)
+    X0 = np.tile(f32_exact(X0s), (1, reps))[:, :B]; U = np.tile(f32_exact(Us), (1, 1, reps))[:, :, :B]
+    X0d = torch.from_numpy(np.ascontiguousarray(X0, dtype=np.float32)).to(gpu)
+    Ud = torch.from_numpy(np.ascontiguousarray(U, dtype=np.float32)).to(gpu)
+    big = ac.rollout(X0d, Ud, 0.01)
+    assert ac.last_launch()[0] == "k_nn_rollout"
+    small = ac.rollout(X0d[:, :64].contiguous(), Ud[:, :, :64].contiguous(), 0.01)
+    assert ac.last_launch()[0].startswith("k_nn_rollout_")
+    want = make_oracle(ac).rollout(X0[:, :64], U[:, :, :64], 0.01)
+    for sl in (slice(0, 64), slice(B - 48 - 64, B - 48)):  # first and last whole period
+        assert block_rel_err(big[:, :, sl].cpu().numpy(), want) < 1e-5
+    assert block_rel_err(big[:, :, :64].cpu().numpy(), small.cpu().numpy()) < 5e-6
+    assert torch.equal(big[:, :, :64], big[:, :, 64 * 1000:64 * 1001])  # same inputs, same outputs, wherever they sit
+
+
 @pytest.mark.parametrize("model,hidden", [("default", None), ("nn", (32, 32))])
 def test_indexing_beyond_2_31_elements(gpu, model, hidden):
     """Maximum sizes: 13 M units make dF/dx a 2.2e9-element array (8.8 GB), past 32-bit element indices.  The inputs
