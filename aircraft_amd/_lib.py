@@ -74,6 +74,7 @@ PROTOTYPES = {
     "ac_shoot_sens_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP, _VP]),
     "ac_state_derivative_sens_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, _VP, _VP, _VP, _VP]),
     "ac_shoot_derivative_sens_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP]),
+    "ac_shoot_derivative_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
     "ac_envelope_f32": (C.c_int, [_VP, _VP, C.c_long, _VP, _VP, _VP]),
     "ac_shoot_envelope_f32": (C.c_int, [_VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP]),
     "ac_envelope_cost_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
@@ -84,6 +85,9 @@ PROTOTYPES = {
     "ac_shoot_hess_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
     "ac_aero_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, _VP, _VP]),
     "ac_traj_cost_f32": (C.c_int, [_VP, _VP, C.c_long, C.c_long, _FP, C.c_float, C.c_float, _VP, _VP]),
+    "ac_best_records_f32": (C.c_int, [_VP, _VP, _VP, _VP, C.c_long, C.c_long, C.c_int, _VP, _VP]),
+    "ac_merge_records_f32": (C.c_int, [_VP, _VP, C.c_long, C.c_long, _VP, _VP]),
+    "ac_ilqr_accept_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, C.c_long, C.c_long, _VP, _VP, _VP, _VP, _VP]),
     "ac_ilqr_backward_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP]),
     "ac_ilqr_cost_f32": (C.c_int, [_VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
     "ac_ilqr_backward_node_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP,

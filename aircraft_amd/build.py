@@ -28,6 +28,21 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_sha() -> str:
+    """Identity of the library BUILD INPUTS (kernel sources, headers, compile flags): stable across rebuilds of the same
+    tree, different as soon as a kernel or a flag changes.  Measurements that are committed and quoted later
+    (profiles/*_pmc_traffic.json) carry it, and bench.py quotes them only for the build they were taken on."""
+    import hashlib
+
+    hh = hashlib.sha256()
+    for f in sources() + sorted(HEADERS):
+        hh.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            hh.update(fh.read())
+    hh.update(repr((CFLAGS, sorted(UNIT_FLAGS.items()))).encode())
+    return hh.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

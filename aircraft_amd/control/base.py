@@ -117,7 +117,7 @@ class MultipleShooting:
             return X[1 : H + 1] - self.propagate(X, U, dt)
         if mode != "implicit":
             raise NotImplementedError("Must choose integration mode from ['implicit', 'explicit']")  # base.py:286
-        f, _, _ = self.derivative_sens(X[1 : H + 1], U)
+        f = self.derivative(X[1 : H + 1], U)  # the residual needs f alone: the forward kernel, no Jacobian blocks
         return X[1 : H + 1] - X[:H] - self._dt_tensor(dt, X) * f
 
     def _dt_tensor(self, dt, X):
@@ -127,6 +127,19 @@ class MultipleShooting:
         if isinstance(dt, torch.Tensor) and dt.numel() > 1:
             return dt.to(device=X.device, dtype=torch.float32)[:, None, :]
         return float(dt)
+
+    def derivative(self, Xn, Un, out=None):
+        """f(x, u) at the H (state, control) pairs Xn (H, 13, B) [a view such as X[1:] is used in place], Un (H, 7, B)."""
+        torch = _torch()
+        lib = self.system._sync()
+        H, B = Un.shape[0], Un.shape[2]
+        assert Xn.is_cuda and Xn.is_contiguous() and Un.is_contiguous() and Xn.shape == (H, self.state_dim, B)
+        assert Un.shape[1] == _lib.NUM_CONTROLS and Xn.dtype == torch.float32 and Un.dtype == torch.float32
+        if out is None:
+            out = torch.empty((H, self.state_dim, B), device=Xn.device, dtype=torch.float32)
+        _lib.check(lib.ac_shoot_derivative_f32(self.system._handle, Xn.data_ptr(), Un.data_ptr(), B, H, out.data_ptr(),
+                                               self.system._stream()), "ac_shoot_derivative_f32")
+        return out
 
     def derivative_sens(self, Xn, Un, out=None):
         """f, Fx = df/dx, Fu = df/du at the H (state, control) pairs Xn (H, 13, B) [a view such as X[1:] is used in

@@ -8,7 +8,7 @@ main/control/control.py:35-70: goal term on the final position, actuation penalt
 
 One iteration = linearise (ac_shoot_sens_f32) -> backward Riccati pass (ac_ilqr_backward_f32) -> closed-loop rollouts for
 every line-search step alpha in ONE launch (ac_rollout_policy_f32) -> cost (ac_ilqr_cost_f32) -> per-instance argmin.
-Everything stays on the device; torch is used for buffers and the final select only.
+Everything stays on the device; torch supplies the buffers only (the acceptance is a HIP kernel too: ac_ilqr_accept_f32).
 """
 from __future__ import annotations
 
@@ -90,7 +90,8 @@ class ILQR(MultipleShooting):
         if self._ws is None or self._ws["key"] != key:
             f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)  # noqa: E731
             self._ws = dict(key=key, F=f(H, 13, B), A=f(H, 13, 13, B), Bm=f(H, 13, 7, B), K=f(H, 7, 13, B), kff=f(H, 7, B),
-                            dV=f(2, B), Xc=f(H + 1, 13, na * B), Uc=f(H, 7, na * B), Jc=f(na * B), J0=f(B))
+                            dV=f(2, B), Xc=f(H + 1, 13, na * B), Uc=f(H, 7, na * B), Jc=f(na * B), J0=f(B), Ja=f(B),
+                            improved=torch.empty((B,), device=dev, dtype=torch.bool))
             if self.hessian_mode == "exact":
                 self._ws.update(Lam=f(H, 13, B), Hz=f(H, 21, 21, B))
                 self.system._sync()
@@ -236,16 +237,21 @@ class ILQR(MultipleShooting):
         if env:
             self.envelope_cost(ws["Xc"], ws["Jc"])
             self.envelope_cost(X, ws["J0"])
-        Jc = ws["Jc"].view(na, B)
-        Jc = torch.where(torch.isfinite(Jc), Jc, torch.full_like(Jc, float("inf")))
-        best, idx = Jc.min(dim=0)
-        improved = best < ws["J0"]
-        col = idx * B + torch.arange(B, device=U.device)
-        Xn = ws["Xc"].index_select(2, col)
-        Un = ws["Uc"].index_select(2, col)
-        X.copy_(torch.where(improved[None, None, :], Xn, X))
-        U.copy_(torch.where(improved[None, None, :], Un, U))
-        return torch.where(improved, best, ws["J0"]), improved
+        return self.accept(ws["Jc"], ws["J0"], ws["Xc"], ws["Uc"], X, U)
+
+    def accept(self, Jc, J0, Xc, Uc, X, U):
+        """Line-search acceptance in ONE launch (`ac_ilqr_accept_f32`): per instance the cheapest finite candidate replaces
+        the iterate (X, U) in place if it beats J0.  Returns (accepted cost (B,), improved (B,) bool)."""
+        torch = _torch()
+        lib = self.system._sync()
+        H, B = U.shape[0], U.shape[2]
+        na = Jc.numel() // B
+        ws = self._workspace(B, U.device)
+        Ja, imp = ws["Ja"], ws["improved"]
+        _lib.check(lib.ac_ilqr_accept_f32(self.system._handle, Jc.data_ptr(), J0.data_ptr(), Xc.data_ptr(), Uc.data_ptr(),
+                                          na, B, H, X.data_ptr(), U.data_ptr(), Ja.data_ptr(), imp.data_ptr(),
+                                          self.system._stream()), "ac_ilqr_accept_f32")
+        return Ja, imp
 
     def solve(self, x0, U0, iters: int = 10, save_to: Optional[str] = None, save_instance: int = 0):
         """Rollout from x0 with U0, then `iters` iLQR iterations.  Returns (X, U, cost history (iters+1, B)).
@@ -254,7 +260,10 @@ class ILQR(MultipleShooting):
         torch = _torch()
         U = U0.clone()
         X = self.rollout(x0, U)
-        hist = [self.trajectory_cost(X, U).clone()]
+        J = self.trajectory_cost(X, U).clone()
+        if self.envelope_weight > 0:  # the same objective as every later entry (iterate() adds the penalty)
+            self.envelope_cost(X, J)
+        hist = [J]
         if save_to:
             self.save_progress(save_to, 0, X, U, save_instance, mode="w")
         for it in range(iters):

@@ -62,6 +62,8 @@ class RecedingHorizon:
             J, _ = s.iterate(self.x0, self.X, self.U)
         if J is None:  # iterations == 0: the loop alone (keep / shift / re-rollout), no solve
             J = s.trajectory_cost(self.X, self.U)
+            if getattr(s, "envelope_weight", 0.0) > 0:  # the objective iterate() reports includes the penalty
+                s.envelope_cost(self.X, J)
         self.cost.copy_(J)
         self.executed.copy_(self.X[1 : self.keep + 1])
         # advance: the state reached after the kept nodes becomes the next initial state

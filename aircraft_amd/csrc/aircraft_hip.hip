@@ -15,6 +15,7 @@
 #include "ac_track.hpp"
 #include "ac_hess.hpp"
 #include "ac_hess_nn.hpp"
+#include "ac_select.hpp"
 
 using namespace ac;
 
@@ -64,8 +65,9 @@ struct ac_handle {
     DevParams dp;
     int device;
     int num_cus;
-    bool no_pair;  // AIRCRAFT_HIP_NO_PAIR=1 (measurement aid): never route a remainder to k_nn_step_sens_pair
-    bool all_pair; // AIRCRAFT_HIP_ALL_PAIR=1 (measurement aid): every unit through k_nn_step_sens_pair
+    // measurement aids, diagnostic flavours only (-DAC_DIAG_ENV; always false in the product library):
+    bool no_pair;  // AIRCRAFT_HIP_NO_PAIR=1: never route a remainder to k_nn_step_sens_pair
+    bool all_pair; // AIRCRAFT_HIP_ALL_PAIR=1: every unit through k_nn_step_sens_pair
     bool has_linear, has_poly, has_mlp;
     MlpPlan plan;
     MlpPlan plan_sens;  // the MFMA sensitivity engines' plan: last layer = [bias][wlt] for MlpEngine::last_valu (ac_set_mlp)
@@ -229,15 +231,18 @@ int ac_create(const ac_params* params, ac_handle** out) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess) h->num_cus = cus;
     }
-    {
+#ifdef AC_DIAG_ENV
+    {   // measurement switches exist in the diagnostic flavours only (build.py --diag / tools/variant_lib.sh -DAC_DIAG_ENV):
+        // the product library's dispatch never depends on the environment
         const char* e = getenv("AIRCRAFT_HIP_NO_PAIR");
         h->no_pair = e && e[0] == '1';
         const char* ea = getenv("AIRCRAFT_HIP_ALL_PAIR");
         h->all_pair = ea && ea[0] == '1';
-#ifdef AC_STAMPS
-        h->no_pair = true;  // the diagnostic flavor passes its stamp buffer through `c`; only k_nn_step_sens knows that
-#endif
     }
+#endif
+#ifdef AC_STAMPS
+    h->no_pair = true;  // the diagnostic flavor passes its stamp buffer through `c`; only k_nn_step_sens knows that
+#endif
     *out = h;
     return AC_OK;
 }
@@ -517,10 +522,12 @@ static int launch_nn_fwd(ac_handle* h, int op, const float* X, const float* U, f
             int rc_ = set_lds_limit(h, kern, lds);                                                                 \
             if (rc_ != AC_OK) return rc_;                                                                          \
             hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->vplan, h->d_vblob, X, U, dt, dtp, n, blk, out); \
+            launched = true;                                                                                       \
         }
         AC_TILED_FWD(32, OP_DERIV) AC_TILED_FWD(32, OP_STEP) AC_TILED_FWD(32, OP_AERO)
         AC_TILED_FWD(64, OP_DERIV) AC_TILED_FWD(64, OP_STEP) AC_TILED_FWD(64, OP_AERO)
 #undef AC_TILED_FWD
+        if (!launched) return fail(AC_ERR_UNSUPPORTED, "no tiled vector-ALU kernel instance for this hidden width");
         note_launch(h, op == OP_DERIV ? "k_nn_fwd_tiled<deriv>" : (op == OP_STEP ? "k_nn_fwd_tiled<step>" : "k_nn_fwd_tiled<aero>"), grid,
                     kBlock, lds);
         AC_HIP(hipGetLastError());
@@ -576,11 +583,10 @@ static int launch_nn_fwd(ac_handle* h, int op, const float* X, const float* U, f
     return AC_OK;
 }
 
-int ac_state_derivative_f32(ac_handle* h, const float* X, const float* U, long n, float* Xdot, void* stream) {
+static int derivative_impl(ac_handle* h, const float* X, const float* U, long n, long blk, float* Xdot, void* stream) {
     AC_ENTER(h);
-    const long blk = n;
     if (h && n == 0) return AC_OK;  // empty batch: nothing to do (pointers may be NULL)
-    if (!h || !X || !U || !Xdot || n < 0) return AC_ERR_BAD_ARG;
+    if (!h || !X || !U || !Xdot || n < 0 || blk <= 0) return AC_ERR_BAD_ARG;
     int rc = model_ready(h);
     if (rc != AC_OK) return rc;
     if (n == 0) return AC_OK;
@@ -591,6 +597,15 @@ int ac_state_derivative_f32(ac_handle* h, const float* X, const float* U, long n
     note_launch(h, "k_state_derivative", grid, kBlock, 0);
     AC_HIP(hipGetLastError());
     return AC_OK;
+}
+
+int ac_state_derivative_f32(ac_handle* h, const float* X, const float* U, long n, float* Xdot, void* stream) {
+    return derivative_impl(h, X, U, n, n > 0 ? n : 1, Xdot, stream);
+}
+
+int ac_shoot_derivative_f32(ac_handle* h, const float* X, const float* U, long B, long H, float* Xdot, void* stream) {
+    if (B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    return derivative_impl(h, X, U, B * H, B > 0 ? B : 1, Xdot, stream);
 }
 
 static int step_impl(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long n, long blk,
@@ -650,15 +665,18 @@ int ac_rollout_f32(ac_handle* h, const float* X0, const float* U, float dt, long
     if (h->dp.p.model_kind == AC_MODEL_NN && !h->use_mfma && h->has_vplan) {
         const int grid = (int)((B + kBlock - 1) / kBlock);
         const int lds = h->vplan.image_floats * 4 + 4 * 64 * (h->vwidth + 4) * 4;
+        bool launched = false;
 #define AC_TILED_ROLL(W_)                                                                                          \
         if (h->vwidth == W_) {                                                                                     \
             auto kern = k_nn_rollout_tiled<W_>;                                                                    \
             int rc_ = set_lds_limit(h, kern, lds);                                                                 \
             if (rc_ != AC_OK) return rc_;                                                                          \
             hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->vplan, h->d_vblob, X0, U, dt, B, H, Xout);   \
+            launched = true;                                                                                       \
         }
         AC_TILED_ROLL(32) AC_TILED_ROLL(64)
 #undef AC_TILED_ROLL
+        if (!launched) return fail(AC_ERR_UNSUPPORTED, "no tiled vector-ALU kernel instance for this hidden width");
         note_launch(h, "k_nn_rollout_tiled", grid, kBlock, lds);
         AC_HIP(hipGetLastError());
         return AC_OK;
@@ -739,15 +757,18 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
             // "MFMA off": the tiled v_pk_fma_f32 engine (ac_mlp_valu.hpp), 16 units per wave, 64 per workgroup
             const int grid = (int)((n + 63) / 64);
             const int lds = h->vplan.image_floats * 4 + 4 * 96 * (h->vwidth + 4) * 4;
+            bool launched = false;
 #define AC_TILED_SENS(W_)                                                                                          \
             if (h->vwidth == W_) {                                                                                 \
                 auto kern = k_nn_step_sens_tiled<W_>;                                                              \
                 int rc_ = set_lds_limit(h, kern, lds);                                                             \
                 if (rc_ != AC_OK) return rc_;                                                                      \
                 hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->vplan, h->d_vblob, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c); \
+                launched = true;                                                                                   \
             }
             AC_TILED_SENS(32) AC_TILED_SENS(64)
 #undef AC_TILED_SENS
+            if (!launched) return fail(AC_ERR_UNSUPPORTED, "no tiled vector-ALU kernel instance for this hidden width");
             note_launch(h, "k_nn_step_sens_tiled", grid, kBlock, lds);
             AC_HIP(hipGetLastError());
             return AC_OK;
@@ -829,15 +850,18 @@ static int deriv_sens_impl(ac_handle* h, const float* X, const float* U, long n,
     if (h->dp.p.model_kind == AC_MODEL_NN && !h->use_mfma && h->has_vplan) {
         const int grid = (int)((n + 63) / 64);
         const int lds = h->vplan.image_floats * 4 + 4 * 96 * (h->vwidth + 4) * 4;
+        bool launched = false;
 #define AC_TILED_DS(W_)                                                                                            \
         if (h->vwidth == W_) {                                                                                     \
             auto kern = k_nn_deriv_sens_tiled<W_>;                                                                 \
             int rc_ = set_lds_limit(h, kern, lds);                                                                 \
             if (rc_ != AC_OK) return rc_;                                                                          \
             hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->vplan, h->d_vblob, X, U, n, blk, Xdot, Fx, Fu); \
+            launched = true;                                                                                       \
         }
         AC_TILED_DS(32) AC_TILED_DS(64)
 #undef AC_TILED_DS
+        if (!launched) return fail(AC_ERR_UNSUPPORTED, "no tiled vector-ALU kernel instance for this hidden width");
         note_launch(h, "k_nn_deriv_sens_tiled", grid, kBlock, lds);
         AC_HIP(hipGetLastError());
         return AC_OK;
@@ -1103,6 +1127,46 @@ int ac_traj_cost_f32(ac_handle* h, const float* X, long B, long H, const float* 
     const int grid = (int)((B + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_traj_cost, grid, kBlock, 0, st, X, B, H, goal3[0], goal3[1], goal3[2], w_track, w_goal, cost);
     note_launch(h, "k_traj_cost", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_best_records_f32(ac_handle* h, const float* cost, const float* X, const float* U, long B, long H, int K,
+                        float* rec, void* stream) {
+    AC_ENTER(h);
+    if (!h || K < 0 || B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    if (K == 0) return AC_OK;
+    if (!cost || !X || !rec || (H > 0 && !U)) return AC_ERR_BAD_ARG;
+    if (K > kMaxBestK) return fail(AC_ERR_BAD_ARG, "ac_best_records_f32: K > 8");
+    if (K > B) return fail(AC_ERR_BAD_ARG, "ac_best_records_f32: K exceeds the number of instances");
+    hipLaunchKernelGGL(k_best_records, K, kSelBlock, 0, (hipStream_t)stream, cost, X, U, B, H, K, rec);
+    note_launch(h, "k_best_records", K, kSelBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_merge_records_f32(ac_handle* h, const float* rec_in, long n, long R, float* rec_out, void* stream) {
+    AC_ENTER(h);
+    if (!h || n < 0 || R < 1) return AC_ERR_BAD_ARG;
+    if (n == 0) return AC_OK;
+    if (!rec_in || !rec_out || rec_in == rec_out) return AC_ERR_BAD_ARG;
+    if (n > 1024) return fail(AC_ERR_BAD_ARG, "ac_merge_records_f32: more than 1024 rows");
+    hipLaunchKernelGGL(k_merge_records, (int)n, 256, 0, (hipStream_t)stream, rec_in, n, R, rec_out);
+    note_launch(h, "k_merge_records", (int)n, 256, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_ilqr_accept_f32(ac_handle* h, const float* Jc, const float* J0, const float* Xc, const float* Uc, int n_alpha,
+                       long B, long H, float* X, float* U, float* Jout, unsigned char* improved, void* stream) {
+    AC_ENTER(h);
+    if (h && B == 0) return AC_OK;
+    if (!h || !Jc || !J0 || !Xc || !X || !Jout || (H > 0 && (!Uc || !U)) || n_alpha < 1 || n_alpha > 8 || B < 0 || H < 0)
+        return AC_ERR_BAD_ARG;
+    const long nrows = (H + 1) * 13 + H * 7;
+    dim3 grid((unsigned)((B + 255) / 256), (unsigned)((nrows + kAcceptRows - 1) / kAcceptRows));
+    hipLaunchKernelGGL(k_ilqr_accept, grid, 256, 0, (hipStream_t)stream, Jc, J0, Xc, Uc, n_alpha, B, H, X, U, Jout, improved);
+    note_launch(h, "k_ilqr_accept", (int)grid.x, 256, 0);
     AC_HIP(hipGetLastError());
     return AC_OK;
 }

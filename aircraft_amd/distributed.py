@@ -8,7 +8,7 @@ collective; the single exchange is one all-gather of every rank's best-K traject
 from __future__ import annotations
 
 import ctypes as C
-from typing import Tuple
+from typing import Optional, Tuple
 
 from . import _lib
 
@@ -40,14 +40,44 @@ def trajectory_cost(system, X, goal, w_track: float = 1.0, w_goal: float = 10.0)
     return cost
 
 
-def pack_records(cost, X, U, k: int):
-    """Best-k (lowest cost) instances of this rank as rows [cost, X(H+1,13) flat, U(H,7) flat]."""
+def _need_device(what, t, system):
+    if not t.is_cuda or system is None:
+        raise _lib.AircraftHipError(
+            f"{what}: device tensors and `system` (the handle that owns the kernels and the stream) are required — "
+            "aircraft_amd has no CPU fallback (the CPU test-suite injects the restatement of oracle/records_oracle.py "
+            "through gather_best(pack=, merge=))")
+
+
+def pack_records(cost, X, U, k: int, system=None):
+    """Best-k (lowest cost; NaN counts as +inf, equal costs by instance index) instances of this rank as rows
+    [cost, X(H+1,13) flat, U(H,7) flat], ascending: ONE launch of the K6 select + pack kernel (`ac_best_records_f32`)
+    straight on the rollout-shaped buffers."""
     torch = _torch()
+    _need_device("pack_records", X, system)
     k = min(int(k), cost.numel())
-    vals, idx = torch.topk(cost, k, largest=False, sorted=True)
-    Xb = X.index_select(2, idx).permute(2, 0, 1).reshape(k, -1)  # (k, (H+1)*13)
-    Ub = U.index_select(2, idx).permute(2, 0, 1).reshape(k, -1)  # (k, H*7)
-    return torch.cat([vals[:, None], Xb, Ub], dim=1).contiguous()
+    H, B = U.shape[0], U.shape[2]
+    R = 1 + (H + 1) * 13 + H * 7
+    lib = system._sync()
+    assert cost.is_cuda and cost.dtype == torch.float32 and cost.is_contiguous() and cost.numel() == B
+    assert X.is_contiguous() and U.is_contiguous() and X.dtype == torch.float32 and U.dtype == torch.float32
+    assert X.shape == (H + 1, 13, B) and U.shape[1] == _lib.NUM_CONTROLS
+    rec = torch.empty((k, R), device=X.device, dtype=torch.float32)
+    _lib.check(lib.ac_best_records_f32(system._handle, cost.data_ptr(), X.data_ptr(), U.data_ptr(), B, H, k,
+                                       rec.data_ptr(), system._stream()), "ac_best_records_f32")
+    return rec
+
+
+def merge_records(rec, system=None):
+    """Rows sorted by cost (column 0; NaN -> +inf; stable): the K * world merge after the all-gather
+    (`ac_merge_records_f32`)."""
+    torch = _torch()
+    _need_device("merge_records", rec, system)
+    lib = system._sync()
+    assert rec.is_contiguous() and rec.dtype == torch.float32
+    out = torch.empty_like(rec)
+    _lib.check(lib.ac_merge_records_f32(system._handle, rec.data_ptr(), rec.shape[0], rec.shape[1], out.data_ptr(),
+                                        system._stream()), "ac_merge_records_f32")
+    return out
 
 
 def unpack_records(rec, H: int):
@@ -75,18 +105,26 @@ def all_gather_records(rec, group=None):
 
 
 def gather_best(X, U, goal, k: int = 1, system=None, cost=None, group=None, w_track: float = 1.0,
-                w_goal: float = 10.0):
-    """Best-k records of every rank, gathered on all ranks and sorted by cost: (cost, X, U) with
-    world*k rows.  `cost` may be supplied; otherwise it is evaluated on the device (needs `system`)
-    or, for host tensors in the CPU test-suite, with the same formula in torch."""
+                w_goal: float = 10.0, timing: Optional[dict] = None, pack=None, merge=None):
+    """Best-k records of every rank, gathered on all ranks and sorted by cost: (cost, X, U) with world*k rows.
+    Three launches and one collective: K6 cost kernel (unless `cost` is supplied), K6 select + pack kernel, ONE
+    all_gather_into_tensor, merge kernel.  `timing` (a dict) receives `gather_ms`: HIP-event time of the whole exchange
+    on this rank's stream (it synchronises — a measurement aid, not for captured loops).
+    `pack` / `merge`: replacements for the two kernels with the same signatures — how the CPU test-suite's gloo ranks
+    (no GPU) drive this function's collective logic with the NumPy restatement; the product never passes them."""
     torch = _torch()
+    ev = None
+    if timing is not None and X.is_cuda:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     if cost is None:
-        if system is not None and X.is_cuda:
-            cost = trajectory_cost(system, X, goal, w_track, w_goal)
-        else:
-            d = X[:, 0:3, :] - torch.as_tensor(goal, dtype=X.dtype, device=X.device)[None, :, None]
-            sq = (d * d).sum(dim=1)  # (H+1, B)
-            cost = w_track * sq.sum(dim=0) + w_goal * sq[-1]
-    rec = all_gather_records(pack_records(cost, X, U, k), group=group)
-    order = torch.argsort(rec[:, 0])
-    return unpack_records(rec[order], U.shape[0])
+        _need_device("gather_best without `cost`", X, system)
+        cost = trajectory_cost(system, X, goal, w_track, w_goal)
+    rec = (pack or pack_records)(cost, X, U, k, system=system)
+    rec = all_gather_records(rec, group=group)
+    rec = (merge or merge_records)(rec, system=system)
+    if ev is not None:
+        ev[1].record()
+        ev[1].synchronize()
+        timing["gather_ms"] = ev[0].elapsed_time(ev[1])
+    return unpack_records(rec, U.shape[0])

@@ -123,6 +123,9 @@ class SixDOF(ABC):
         if getattr(self, "_handle", None):
             _lib.load().ac_destroy(self._handle)
             self._handle = C.c_void_p()
+            # the workspaces died with the handle: a re-created one must be reserved again
+            self._hess_reserved = 0
+            self._installed_key = None
 
     def __del__(self):
         try:

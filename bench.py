@@ -180,7 +180,9 @@ def cpu_baseline(ac, X, U, dt, seconds):
         usable = os.cpu_count() or 1
     all_threads = min(usable, orc.num_threads()) if orc.num_threads() > 0 else usable
 
-    def leg(threads, budget):
+    kept = {}
+
+    def leg(threads, budget, keep=False):
         orc.set_num_threads(threads)
         cores = orc.num_threads()
         n_probe = min(X.shape[1], 64 * cores)
@@ -191,16 +193,47 @@ def cpu_baseline(ac, X, U, dt, seconds):
         reps = max(1, int(np.ceil(rate * budget / n)))  # repeat the sample until ~`budget` seconds of CPU work
         t0 = time.perf_counter()
         for _ in range(reps):
-            o.step_sens(X[:, :n], U[:, :n], dt)
+            outs = o.step_sens(X[:, :n], U[:, :n], dt)
         el = time.perf_counter() - t0
+        if keep:  # the oracle's results on the first n units: checked against the timed GPU outputs (parity_in_run)
+            kept.update(n=n, Xn=outs[0], A=outs[1], B=outs[2])
         return {"value": n * reps / el, "unit": "horizon-steps/s", "cores": cores, "kind": "port",
                 "sample": f"{reps} x {n} of the same (x_k,u_k) units, step+A,B,c sensitivities, float64 C++ oracle "
                           f"(g++ -O3 -mavx2, OpenMP {cores} thread{'s' if cores > 1 else ''}), {el:.1f} s"}
 
-    res = leg(all_threads, 0.5 * seconds)
+    res = leg(all_threads, 0.5 * seconds, keep=True)
     res["one_core"] = leg(1, 0.5 * seconds)
     orc.set_num_threads(all_threads)
-    return res
+    return res, kept
+
+
+def parity_in_run(kept, F, A, Bm, tol=1e-5):
+    """Compare the outputs the TIMED run left in HBM (F, A, B of the last timed sweep) with the float64 oracle's results
+    on the same units (the cpu_baseline sample: the first n units in node-major order).  Same metrics as the parity
+    tests: block-relative state error (blocks p, v, q, omega; floors 1 m, 1 m/s, 1, 0.1 rad/s) and, per unit, the
+    max-norm relative error of its A and B blocks."""
+    import numpy as np
+
+    n = kept["n"]
+    H, _, B = F.shape
+    Fg = F.permute(1, 0, 2).reshape(13, H * B)[:, :n].double().cpu().numpy()
+    Ag = A.permute(1, 2, 0, 3).reshape(13, 13, H * B)[:, :, :n].double().cpu().numpy()
+    Bg = Bm.permute(1, 2, 0, 3).reshape(13, 7, H * B)[:, :, :n].double().cpu().numpy()
+    worst = 0.0
+    for sl, floor in ((slice(0, 3), 1.0), (slice(3, 6), 1.0), (slice(6, 10), 1.0), (slice(10, 13), 0.1)):
+        d = np.abs(Fg[sl] - kept["Xn"][sl]).max(axis=0)
+        worst = max(worst, float((d / np.maximum(np.abs(kept["Xn"][sl]).max(axis=0), floor)).max()))
+
+    def unit_rel(a, ref):
+        d = np.abs(a - ref).reshape(-1, n).max(axis=0)
+        return float((d / np.maximum(np.abs(ref).reshape(-1, n).max(axis=0), 1e-300)).max())
+
+    ea, eb = unit_rel(Ag, kept["A"]), unit_rel(Bg, kept["B"])
+    finite = bool(np.isfinite(Fg).all() and np.isfinite(Ag).all() and np.isfinite(Bg).all())
+    return {"units": int(n), "state_block_rel_max": worst, "A_unit_rel_max": ea, "B_unit_rel_max": eb, "tol": tol,
+            "ok": bool(finite and worst <= tol and ea <= tol and eb <= tol),
+            "note": "timed run's F, A, B (last sweep, still in HBM) vs the float64 oracle on the same first `units` "
+                    "(x_k,u_k) units; every unit on its own (max norm), nothing masked"}
 
 
 # ---- one rank ----------------------------------------------------------------------------------------------------
@@ -288,8 +321,9 @@ def run_rank(args):
             ev[i][0].record()          # HIP events on the stream the kernel is launched on (torch's current stream)
             ms.linearise(X, U, out=out)
             ev[i][1].record()
+        gather = {}
         if world > 1:
-            best = gather_best(X, U, goal, k=1, system=ac)
+            best = gather_best(X, U, goal, k=1, system=ac, timing=gather)   # cost + select/pack kernels, ONE all-gather, merge
             assert best[0].numel() == world
         torch.cuda.synchronize()
         if world > 1:
@@ -301,7 +335,7 @@ def run_rank(args):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-        return {"elapsed": elapsed, "kern_ms": kern_ms, "launch": launch, "X": X, "U": U, "F": F, "Xh": Xh, "Uh": Uh, "B": B}
+        return {"elapsed": elapsed, "kern_ms": kern_ms, "launch": launch, "gather_ms": gather.get("gather_ms"), "X": X, "U": U, "F": F, "A": A, "Bm": Bm, "Xh": Xh, "Uh": Uh, "B": B}
 
     F_mlp = mlp.flops_forward()
     flops_unit = 24 * F_mlp + 30000          # SURVEY.md §8d contract figure (4 stages x (1 value + 5 tangents))
@@ -343,15 +377,25 @@ def run_rank(args):
     # on a known-byte-count kernel of the same access pattern): collected separately with rocprofv3 --pmc and committed
     # under profiles/; it applies to the default workload only.
     traffic, traffic_src = None, None
-    for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        tpath = os.path.join(ROOT, "profiles", cand)
-        if os.path.exists(tpath) and (B, H, hidden) == (4096, 50, (128, 128, 128, 128)) and not args.no_mfma:
-            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
-            traffic_src = f"profiles/{cand}"
+    from aircraft_amd.build import source_sha
+    this_build = source_sha()
+    if (B, H, hidden) == (4096, 50, (128, 128, 128, 128)) and not args.no_mfma and not os.environ.get("AIRCRAFT_HIP_LIB"):
+        for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", cand)
+            if not os.path.exists(tpath):
+                continue
+            rec = json.load(open(tpath))
+            if rec.get("source_sha") == this_build:   # measured on THIS build's kernels: quote it
+                traffic = rec["traffic_bytes_per_launch"]
+                traffic_src = f"profiles/{cand}, source_sha {this_build}"
+            else:                                      # a stale figure would mislabel this build: say so instead
+                traffic_src = (f"none for this build (source_sha {this_build}); last recorded: profiles/{cand} = "
+                               f"{rec['traffic_bytes_per_launch']:.4g} B at source_sha {rec.get('source_sha', 'unrecorded')}")
             break
     achieved_tflops = flops_unit * B * H / (kern_ms * 1e-3) / 1e12
     achieved_gbs = bytes_unit * B * H / (kern_ms * 1e-3) / 1e9
 
+    parity_failed = False
     if rank == 0:
         scaling = modes[0]
         res = {
@@ -367,7 +411,7 @@ def run_rank(args):
                        "parallelism": f"instances sharded x{world}, one all-gather of best records per solve"},
             "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                         "traffic_unit": f"HBM bytes per launch (PMC, {traffic_src})" if traffic_src else None,
+                         "traffic_unit": f"HBM bytes per launch (PMC: {traffic_src})" if traffic_src else None,
                          "algorithmic_bytes_per_launch": bytes_unit * B * H,
                          "kernel": name, "kernel_ms": kern_ms, "grid": grid, "block": block, "lds_bytes": lds,
                          "kernel_note": "kernel_ms spans the whole step (HIP events around one ac_shoot_sens_f32 call, rank 0): "
@@ -377,11 +421,16 @@ def run_rank(args):
                          "flops_per_unit": flops_unit, "hbm_bytes_per_unit": bytes_unit,
                          "hbm_achieved_GBs": achieved_gbs, "hbm_frac": achieved_gbs / PEAK_HBM_GBS},
         }
+        if world > 1:
+            res["gather_ms"] = primary["gather_ms"]
+            res["gather_note"] = ("rank 0, HIP events around the path's one exchange, once per solve inside the timed region: "
+                                  "k_traj_cost + k_best_records (select + pack) + one all_gather_into_tensor of the "
+                                  f"{(1 + (H + 1) * 13 + H * 7) * 4} B record per rank + k_merge_records")
         if "strong" in results and scaling != "strong":
             s = results["strong"]
             res["strong"] = {"value": s["value"], "unit": "horizon-steps/s", "scaling": "strong",
                              "ms_per_step": s["elapsed"] / args.steps * 1e3, "batch_total": args.batch,
-                             "batch_per_gpu": s["B"], "units_per_step": s["units_per_step"], "kernel_ms_rank0": s["kern_ms"],
+                             "batch_per_gpu": s["B"], "units_per_step": s["units_per_step"], "kernel_ms_rank0": s["kern_ms"], "gather_ms": s["gather_ms"],
                              "note": "the SAME B x H units as the 1-GPU run, sharded over the ranks (the metric's wording); "
                                      "speed-up over N=1 = this value / the N=1 run's value"}
         res["alongside"] = {
@@ -393,15 +442,24 @@ def run_rank(args):
         if world == 1 and not args.no_extras:
             res["alongside"].update(extras(ac, ms, X, U, dev))
         if not args.no_cpu_baseline and world == 1:
-            Xh, Uh = primary["Xh"], primary["Uh"]
+            # the SAME numbers the GPU got: rounded to fp32 once, handed to the float64 oracle
+            Xh = primary["Xh"].astype(np.float32).astype(np.float64)
+            Uh = primary["Uh"].astype(np.float32).astype(np.float64)
             Xs = Xh[:H].transpose(1, 0, 2).reshape(13, H * B)
             Us = Uh.transpose(1, 0, 2).reshape(7, H * B)
-            res["cpu_baseline"] = cpu_baseline(ac, np.ascontiguousarray(Xs), np.ascontiguousarray(Us), dt,
-                                               args.cpu_seconds)
+            # the alongside passes above wrote F (forward shooting) again — bit-identical by construction, but the
+            # check is on what the timed kernel itself produces: one more sweep of it, outside the timed region
+            ms.linearise(X, U, out=(Fbuf, primary["A"], primary["Bm"], None)); torch.cuda.synchronize()
+            res["cpu_baseline"], kept = cpu_baseline(ac, np.ascontiguousarray(Xs), np.ascontiguousarray(Us), dt,
+                                                     args.cpu_seconds)
+            res["parity_in_run"] = parity_in_run(kept, Fbuf, primary["A"], primary["Bm"])
+            parity_failed = not res["parity_in_run"]["ok"]
         print(json.dumps(res), flush=True)
+        if parity_failed:
+            log(f"[bench] PARITY FAILURE: {res['parity_in_run']}")
     if world > 1:
         dist.destroy_process_group()
-    return 0
+    return 5 if parity_failed else 0
 
 
 def main(argv=None):

@@ -74,7 +74,7 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     X, U, hist = solver.solve(x0, U0, iters=args.iters)
-    c, Xb, Ub = gather_best(X, U, None, k=args.topk, cost=hist[-1])   # the one collective
+    c, Xb, Ub = gather_best(X, U, None, k=args.topk, cost=hist[-1].contiguous(), system=ac)   # the one collective
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if rank == 0:

@@ -143,6 +143,9 @@ int ac_shoot_sens_f32(ac_handle* h, const float* X, const float* U, float dt, co
  * Fu [H][13][7][B]. */
 int ac_state_derivative_sens_f32(ac_handle* h, const float* X, const float* U, long n, float* Xdot, float* Fx, float* Fu,
                                  void* stream);
+/* x_dot alone on H nodes of rollout-shaped X [>=H][13][B], U [H][7][B] in place -> Xdot [H][13][B]: the residual of the
+ * implicit defect row (control/base.py:282-284) needs f(x_{k+1}, u_k) but no Jacobian. */
+int ac_shoot_derivative_f32(ac_handle* h, const float* X, const float* U, long B, long H, float* Xdot, void* stream);
 int ac_shoot_derivative_sens_f32(ac_handle* h, const float* X, const float* U, long B, long H, float* Xdot, float* Fx,
                                  float* Fu, void* stream);
 
@@ -210,6 +213,16 @@ int ac_aero_f32(ac_handle* h, const float* X, const float* U, long n, float* out
 int ac_traj_cost_f32(ac_handle* h, const float* X, long B, long H, const float* goal3, float w_track, float w_goal,
                      float* cost, void* stream);
 
+/* Second half of K6: the per-rank best-K select and the record pack in ONE launch.  cost [B] (device; NaN counts as
+ * +inf, equal costs are ordered by instance index), X [H+1][13][B], U [H][7][B] rollout-shaped, 1 <= K <= min(8, B);
+ * rec [K][1 + (H+1)*13 + H*7] = rows [cost, X(H+1,13) node-major, U(H,7) node-major] in ascending cost — the block each
+ * rank hands to the path's one all-gather (8 056 B per row at H = 100). */
+int ac_best_records_f32(ac_handle* h, const float* cost, const float* X, const float* U, long B, long H, int K,
+                        float* rec, void* stream);
+/* The gathered rows of all ranks sorted by cost: rec_in [n][R] -> rec_out [n][R] (n <= 1024 = K * world, column 0 is
+ * the key; NaN -> +inf; stable).  rec_out must not alias rec_in. */
+int ac_merge_records_f32(ac_handle* h, const float* rec_in, long n, long R, float* rec_out, void* stream);
+
 /* ---- batched iLQR / Gauss-Newton sweep on (F, A, B)  (build-side) ---------------------------
  * Plays the `loss` and control-limit roles of ControlProblem (control/base.py:323-337, control/aircraft.py:29-41,
  * main/control/control.py:35-70) for B independent instances; the reference itself hands the NLP to IPOPT.
@@ -234,6 +247,14 @@ int ac_ilqr_cost_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* X, con
 int ac_rollout_policy_f32(ac_handle* h, const ac_ilqr_cost* limits, const float* X0, const float* Xnom,
                           const float* U, const float* K, const float* kff, const float* alphas, int n_alpha, float dt,
                           long B, long H, float* Xout, float* Uout, void* stream);
+
+/* Line-search acceptance, one launch: candidate a of instance b is column a*B + b of Xc [H+1][13][n_alpha*B],
+ * Uc [H][7][n_alpha*B] (the layout ac_rollout_policy_f32 writes) with cost Jc [n_alpha*B]; J0 [B] is the cost of the
+ * current iterate X [H+1][13][B], U [H][7][B].  Per instance: best = min_a Jc (non-finite costs never win, ties -> the
+ * lowest a); if best < J0 the candidate's columns replace the iterate's IN PLACE.  Jout [B] = the accepted cost,
+ * improved [B] = 0/1 bytes (may be NULL). */
+int ac_ilqr_accept_f32(ac_handle* h, const float* Jc, const float* J0, const float* Xc, const float* Uc, int n_alpha,
+                       long B, long H, float* X, float* U, float* Jout, unsigned char* improved, void* stream);
 
 /* Per-node, per-instance state cost for the two calls above (device arrays [H+1][13][Bn], node H = terminal):
  *   l_k(x) = 1/2 sum_j node_q[k][j] (x_j - node_xref[k][j])^2 + node_glin[k] . x

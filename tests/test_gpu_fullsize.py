@@ -171,7 +171,7 @@ def test_cfg4_shard_solve_cost_topk_and_gather(gpu):
     assert (np.diff(h[:, fin], axis=0) <= 1e-6 * np.abs(h[:-1, fin]) + 1e-6).all()  # monotone per instance
     assert np.median(h[-1, fin] / h[0, fin]) < 0.9
     # the one exchange: best-k by the solver's own cost, and by the K6 goal-distance kernel
-    c, Xb, Ub = gather_best(X, U, None, k=k, cost=hist[-1])
+    c, Xb, Ub = gather_best(X, U, None, k=k, cost=hist[-1].contiguous(), system=ac)
     assert c.shape == (k,) and Xb.shape == (k, H + 1, 13) and Ub.shape == (k, H, 7)
     order = torch.argsort(torch.nan_to_num(hist[-1], nan=float("inf")))[:k]
     assert torch.equal(c, hist[-1][order]) and torch.equal(Xb[0], X[:, :, order[0]]) and torch.equal(Ub[0], U[:, :, order[0]])
@@ -353,3 +353,68 @@ def test_remainder_wave_pair_kernel_is_bit_identical(gpu, hidden, n):
     whole = ac.step_sens(Xp, Up, 0.01)
     for got, want in zip(ragged, whole):
         assert torch.equal(got, want[..., :n])
+
+
+@pytest.mark.parametrize("substeps", [1, 10])
+def test_cfg2_full_size_mfma_off_every_unit_against_the_oracle(gpu, substeps):
+    """BASELINE configs[1] at its full size: B = 256 instances x H = 50 nodes = 12 800 units, 5-64-64-64-6 surrogate,
+    use_mfma = 0 (the tiled v_pk_fma_f32 engine), through MultipleShooting.linearise — EVERY unit's x+, A, B, c against the
+    float64 oracle (one RK4 step per node, and the same dt in 10 sub-steps)."""
+    from aircraft_amd.control import MultipleShooting
+
+    ac = make_aircraft("nn", hidden=(64, 64, 64), use_mfma=False, substeps=substeps)
+    B, H = 256, 50
+    ms = MultipleShooting(system=ac, dt=0.01, num_nodes=H, opts={"quaternion": "integration"})
+    Xh, Uh, X, U = _problem(B, H, gpu, seed=2)
+    F, A, Bm, c = ms.linearise(X, U)
+    assert ac.last_launch()[0].startswith("k_nn_step_sens_tiled")
+    Xs = np.ascontiguousarray(Xh[:H].transpose(1, 0, 2).reshape(13, H * B))
+    Us = np.ascontiguousarray(Uh.transpose(1, 0, 2).reshape(7, H * B))
+    Xr, Ar, Br, cr = make_oracle(ac).step_sens(Xs, Us, 0.01)
+    n = H * B
+    Fg = F.cpu().numpy().transpose(1, 0, 2).reshape(13, n)
+    e = block_rel_err(Fg, Xr)
+    parity_report(f"cfg2_full[{substeps}]", block="F", units=n, block_rel_max=e)
+    assert e < 1e-5
+    for key, g, w in (("A", A.cpu().numpy().transpose(1, 2, 0, 3).reshape(13, 13, n), Ar),
+                      ("B", Bm.cpu().numpy().transpose(1, 2, 0, 3).reshape(13, 7, n), Br),
+                      ("c", c.cpu().numpy().transpose(1, 0, 2).reshape(13, n), cr)):
+        eu, eb = unit_max_rel(g, w), unit_rowblock_rel(g, w)
+        parity_report(f"cfg2_full[{substeps}]", block=key, units=n, unit_rel_max=float(eu.max()), rowblock_rel_max=float(eb.max()))
+        assert eu.max() < 1e-5 and eb.max() < 1e-4, (key, float(eu.max()), float(eb.max()))
+
+
+def test_cfg5_full_size_graph_replay_of_1000_solves(gpu):
+    """BASELINE configs[4] at its full size: the receding-horizon closed loop at B = 1024, H = 50 (4x128 surrogate, 2 iLQR
+    iterations per solve, overlap 30), one cycle captured into a hipGraph and replayed 1000 times: the first 20 cycles
+    equal the eager loop bit for bit, the executed history of all 1000 is finite and continuous."""
+    import torch
+    from aircraft_amd.control import ILQR, QuadraticCost, RecedingHorizon
+
+    B, H = 1024, 50
+    ac = make_aircraft("nn", hidden=(128, 128, 128, 128))
+    cost = QuadraticCost.goal((30.0, 0.5), w_goal=1.0, height=-200.0, w_lateral_speed=0.5, r=0.5, reg=1.0)
+    il = ILQR(system=ac, dt=0.01, num_nodes=H, cost=cost, alphas=(1.0, 0.5, 0.1))
+    from aircraft_amd.synthetic import near_trim_problem
+    X0, _ = near_trim_problem(B, H, seed=11)
+    x0 = torch.from_numpy(np.ascontiguousarray(X0, dtype=np.float32)).to(gpu)
+    U0 = torch.zeros((H, 7, B), device=gpu)
+    eager = RecedingHorizon(il, overlap=30, iterations=2).allocate(x0, U0)
+    he = eager.run(20, record=True)
+    il2 = ILQR(system=ac, dt=0.01, num_nodes=H, cost=cost, alphas=(1.0, 0.5, 0.1))
+    graph = RecedingHorizon(il2, overlap=30, iterations=2).allocate(x0, U0).capture()
+    hg = graph.run(20, record=True)
+    assert he.shape == (20 * 20 + 1, 13, B)
+    assert torch.equal(he, hg) and torch.equal(eager.x0, graph.x0) and torch.equal(eager.U, graph.U)
+    # ... and the remaining 980 replays, keeping the executed states of every cycle on the device (1000 x 20 x 13 x 1024 fp32 = 1 GB)
+    rest = graph.run(980, record=True)
+    assert rest.shape == (980 * 20 + 1, 13, B) and torch.equal(rest[0], hg[-1])
+    hist = torch.cat([hg, rest[1:]])
+    fin = torch.isfinite(hist).all(dim=1).all(dim=0)  # per instance
+    parity_report("cfg5_full_replay", instances=B, finite_instances=int(fin.sum()), solves=1000)
+    assert float(fin.float().mean()) >= 0.99, int(fin.sum())
+    h = hist[:, :, fin]
+    step = (h[1:, 0:3] - h[:-1, 0:3]).norm(dim=1)
+    speed = h[:-1, 3:6].norm(dim=1)
+    assert float((step - speed * 0.01).abs().max()) < 0.05   # continuity: one dt apart, never a jump
+    assert float((h[:, 6:10].norm(dim=1) - 1).abs().max()) < 1e-5

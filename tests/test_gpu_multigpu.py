@@ -78,7 +78,8 @@ def test_gather_best_on_device_records(gpu):
     X = ac.rollout(torch.from_numpy(X0).float().to(gpu), Ud, 0.01)
     goal = torch.tensor([150.0, 10.0, -190.0], device=gpu)
     cost = trajectory_cost(ac, X, goal)
-    rec = pack_records(cost, X, Ud, k)
+    rec = pack_records(cost, X, Ud, k, system=ac)
+    assert ac.last_launch()[0] == "k_best_records"
     assert rec.is_cuda and rec.shape == (k, 1 + (H + 1) * 13 + H * 7)
     c, Xb, Ub = unpack_records(rec, H)
     order = torch.argsort(_torch_cost(X, goal.tolist(), 1.0, 10.0))[:k]
@@ -87,6 +88,79 @@ def test_gather_best_on_device_records(gpu):
         assert torch.equal(Xb[i], X[:, :, b]) and torch.equal(Ub[i], Ud[:, :, b]) and c[i] == cost[b]
     c2, Xb2, Ub2 = gather_best(X, Ud, goal, k=k, system=ac)
     assert torch.equal(c2, c) and torch.equal(Xb2, Xb) and torch.equal(Ub2, Ub)
+
+
+@pytest.mark.parametrize("B,H,k", [(512, 20, 4), (16384, 100, 8), (2048, 100, 1), (9, 3, 8), (8, 1, 8), (70001, 2, 5)])
+def test_best_records_kernel_equals_torch_topk(gpu, B, H, k):
+    """K6's second half (ac_best_records_f32: per-rank best-K select + record pack in one launch) bit-equal to
+    torch.topk + index_select + permute + cat on the same buffers; NaN costs count as +inf; equal costs are ordered by
+    instance index (checked against the NumPy restatement, torch.topk leaves ties unspecified); then the merge kernel
+    against a stable argsort."""
+    import torch
+    import records_oracle
+    from aircraft_amd.distributed import merge_records, pack_records
+
+    ac = make_aircraft("default")
+    g = torch.Generator(device="cpu").manual_seed(B + H)
+    X = torch.randn(H + 1, 13, B, generator=g).to(gpu); U = torch.randn(H, 7, B, generator=g).to(gpu)
+    cost = torch.rand(B, generator=g).to(gpu) * 100
+    cost[3 % B] = float("nan")                      # a crashed rollout never wins ...
+    if B > 600:
+        cost[500] = float("-inf"); cost[77] = float("inf")
+    rec = pack_records(cost, X, U, k, system=ac)
+    san = torch.nan_to_num(cost, nan=float("inf"), posinf=float("inf"), neginf=float("-inf"))
+    vals, idx = torch.topk(san, k, largest=False, sorted=True)
+    want = torch.cat([vals[:, None], X.index_select(2, idx).permute(2, 0, 1).reshape(k, -1),
+                      U.index_select(2, idx).permute(2, 0, 1).reshape(k, -1)], dim=1)
+    assert torch.equal(rec, want)                   # bit-equal, including the record layout
+    assert not torch.isnan(rec[:, 0]).any()         # ... unless K reaches it, and then as +inf
+    # ties: quantised costs, many equal values -> index order decides (the restatement's order)
+    tied = (cost * 0.05).floor().nan_to_num(nan=7.0)
+    rec_t = pack_records(tied, X, U, k, system=ac)
+    want_t = records_oracle.pack_records(tied.cpu(), X.cpu(), U.cpu(), k)
+    assert torch.equal(rec_t.cpu(), want_t)
+    # merge: K * world gathered rows, sorted by cost, stable; NaN last
+    rows = torch.cat([rec_t, rec, rec_t.flip(0)]).contiguous()
+    rows[1, 0] = float("nan")
+    merged = merge_records(rows, system=ac)
+    assert ac.last_launch()[0] == "k_merge_records"
+    assert torch.equal(merged.cpu(), records_oracle.merge_records(rows.cpu()))
+    # argument checks: K > 8, K > B, aliasing
+    lib, hnd, st = ac._sync(), ac._handle, ac._stream()
+    assert lib.ac_best_records_f32(hnd, cost.data_ptr(), X.data_ptr(), U.data_ptr(), B, H, 9, rec.data_ptr(), st) == -1
+    assert lib.ac_best_records_f32(hnd, cost.data_ptr(), X.data_ptr(), U.data_ptr(), 2, H, 3, rec.data_ptr(), st) == -1
+    assert lib.ac_best_records_f32(hnd, None, None, None, 0, H, 0, None, st) == 0
+    assert lib.ac_merge_records_f32(hnd, rows.data_ptr(), rows.shape[0], rows.shape[1], rows.data_ptr(), st) == -1
+
+
+@pytest.mark.parametrize("B,H,na", [(24, 30, 3), (1024, 50, 3), (300, 7, 8), (1, 1, 1)])
+def test_line_search_accept_kernel(gpu, B, H, na):
+    """ac_ilqr_accept_f32 (per-instance argmin over the candidates + conditional in-place copy) against the NumPy
+    restatement: NaN / inf candidates never win, ties take the lowest alpha index, non-improving instances keep their
+    iterate bit for bit."""
+    import ctypes as C
+    import torch
+    import records_oracle
+
+    ac = make_aircraft("default")
+    lib = ac._sync()
+    g = torch.Generator(device="cpu").manual_seed(11 * B + na)
+    Xc = torch.randn(H + 1, 13, na * B, generator=g).to(gpu); Uc = torch.randn(H, 7, na * B, generator=g).to(gpu)
+    X = torch.randn(H + 1, 13, B, generator=g).to(gpu); U = torch.randn(H, 7, B, generator=g).to(gpu)
+    Jc = (torch.rand(na * B, generator=g) * 4).round().to(gpu)   # few distinct values: ties across alphas
+    J0 = torch.full((B,), 2.0, device=gpu)
+    Jc[0] = float("nan")
+    if B > 5:
+        Jc[1] = float("-inf"); Jc[2] = float("inf"); J0[4] = float("nan")
+    wJ, wimp, wX, wU = records_oracle.accept(Jc.cpu().numpy(), J0.cpu().numpy(), Xc.cpu().numpy(), Uc.cpu().numpy(),
+                                             X.cpu().numpy(), U.cpu().numpy())
+    Jout = torch.empty(B, device=gpu); imp = torch.zeros(B, device=gpu, dtype=torch.bool)
+    rc = lib.ac_ilqr_accept_f32(ac._handle, Jc.data_ptr(), J0.data_ptr(), Xc.data_ptr(), Uc.data_ptr(), na, B, H,
+                                X.data_ptr(), U.data_ptr(), Jout.data_ptr(), imp.data_ptr(), ac._stream())
+    assert rc == 0
+    assert np.array_equal(imp.cpu().numpy(), wimp) and 0 < wimp.sum() <= B
+    assert np.array_equal(Jout.cpu().numpy(), wJ, equal_nan=True)
+    assert np.array_equal(X.cpu().numpy(), wX) and np.array_equal(U.cpu().numpy(), wU)
 
 
 def _run_bench(extra, env_extra, timeout=600):
@@ -116,8 +190,9 @@ def test_bench_two_rank_rehearsal_on_one_gpu(gpu):
 
 def test_bench_refuses_a_mislabelled_run(gpu):
     """One rank launched as if it were one of two (--gpus 2 under WORLD_SIZE=1) must fail, not print n_gpus 1."""
-    r = _run_bench(["--gpus", "2"], {})
-    # without the rehearsal switches a one-GPU box cannot host two ranks: every rank exits 3, the parent relays it
+    # the child sees ONE device whatever the box has (on a 2/4/8-GPU node the self-launch would legitimately succeed):
+    # without the rehearsal switches one GPU cannot host two ranks: every rank exits 3, the parent relays it
+    r = _run_bench(["--gpus", "2"], {"HIP_VISIBLE_DEVICES": "0", "ROCR_VISIBLE_DEVICES": "0"})
     assert r.returncode != 0 and "need" in r.stderr
     env = {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}
     e = dict(os.environ); e.update(env)
