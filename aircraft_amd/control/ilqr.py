@@ -52,6 +52,21 @@ class QuadraticCost:
         c.qf, c.x_goal = qf, xg
         return c
 
+    @staticmethod
+    def cruise(w_lateral_speed=0.5, w_attitude=5.0, w_rate=0.2, r=0.5, reg=1.0):
+        """A regulator without a goal point, for closed loops that run for minutes: hold the heading north (v_east -> 0,
+        q -> identity, i.e. wings level, nose on the horizon, yaw 0), damp the body rates, penalise actuation; height and
+        along-track position are free (a glider sinks)."""
+        c = QuadraticCost(r=[r] * 7, reg=reg)
+        q = [0.0] * 13
+        q[4] = w_lateral_speed
+        q[6] = q[7] = q[8] = w_attitude   # vector part of q (xyzw) -> 0
+        q[10] = q[11] = q[12] = w_rate
+        xr = [0.0] * 13
+        xr[9] = 1.0
+        c.q, c.qf, c.x_ref, c.x_goal = q, list(q), xr, list(xr)
+        return c
+
     def struct(self) -> "_lib.IlqrCost":
         s = _lib.IlqrCost()
         for name, n in (("q", 13), ("qf", 13), ("r", 7), ("x_ref", 13), ("x_goal", 13), ("u_min", 7), ("u_max", 7)):

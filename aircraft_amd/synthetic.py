@@ -99,3 +99,23 @@ def near_trim_problem(B, H, seed=42):
         cur = np.clip(cur + rng.normal(0, 0.2, (3, B)), -2, 2)
         U[k, :3] = cur
     return X, U
+
+
+def cruise_problem(B, seed=42):
+    """B gliders near trim heading roughly north (+x) at 200 m: initial states of a closed loop that can run for minutes
+    (the receding-horizon regulator of QuadraticCost.cruise holds heading and wings level while the glider sinks)."""
+    rng = np.random.default_rng(seed)
+    X = np.zeros((13, B))
+    X[0] = rng.uniform(-20, 20, B)
+    X[1] = rng.uniform(-20, 20, B)
+    X[2] = rng.uniform(-220, -180, B)
+    V = rng.uniform(45, 60, B)
+    al = np.deg2rad(rng.uniform(-1, 1, B))
+    be = np.deg2rad(rng.uniform(-1, 1, B))
+    vb = np.stack([V * np.cos(al) * np.cos(be), V * np.sin(be), V * np.sin(al) * np.cos(be)])
+    q = quat_from_euler(np.deg2rad(rng.uniform(-10, 10, B)), np.deg2rad(rng.uniform(-3, 3, B)),
+                        np.deg2rad(rng.uniform(-10, 10, B)))
+    X[3:6] = quat_rotate(q, vb)
+    X[6:10] = q
+    X[10:13] = rng.normal(0.0, 0.03, (3, B))
+    return X

@@ -95,7 +95,9 @@ def test_implicit_defect_rows_and_blocks(gpu, name):
     # explicit rows of the same trajectory are (near) zero, implicit ones differ from them at O(dt^2)
     assert float(ms.defects(X, Ud, integration="explicit").abs().max()) < 1e-4
     r2, Jn, Ju, jdt = ms.linearise_implicit(X, Ud)
-    assert torch.equal(r2, r)
+    # defects() takes f from the forward kernel, linearise_implicit() from the value part of the derivative-sensitivity
+    # kernel: the same fp32 arithmetic up to the order of a few roundings
+    assert float((r2 - r).abs().max()) <= 2e-6 * max(float(X.abs().max()), 1.0)
     eye = np.eye(13)[None, :, :, None]
     Jn_w = eye - dt * Fxr.reshape(13, 13, H, B).transpose(2, 0, 1, 3)
     Ju_w = -dt * Fur.reshape(13, 7, H, B).transpose(2, 0, 1, 3)

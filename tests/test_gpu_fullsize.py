@@ -384,37 +384,46 @@ def test_cfg2_full_size_mfma_off_every_unit_against_the_oracle(gpu, substeps):
         assert eu.max() < 1e-5 and eb.max() < 1e-4, (key, float(eu.max()), float(eb.max()))
 
 
-def test_cfg5_full_size_graph_replay_of_1000_solves(gpu):
-    """BASELINE configs[4] at its full size: the receding-horizon closed loop at B = 1024, H = 50 (4x128 surrogate, 2 iLQR
-    iterations per solve, overlap 30), one cycle captured into a hipGraph and replayed 1000 times: the first 20 cycles
-    equal the eager loop bit for bit, the executed history of all 1000 is finite and continuous."""
+@pytest.mark.parametrize("model", ["cfg3_4x128", "poly"])
+def test_cfg5_full_size_graph_replay_of_1000_solves(gpu, model):
+    """BASELINE configs[4] at its full size: the receding-horizon closed loop at B = 1024, H = 50 (2 iLQR iterations per
+    solve, overlap 30), one cycle captured into a hipGraph and replayed 1000 times — 200 s of flight per instance.  The first
+    20 cycles equal the eager loop bit for bit; the executed history of all 1000 is finite and continuous on EVERY instance.
+    Problem: gliders near trim under a goal-free regulator (hold heading and wings level, sink freely) — a fixed goal point
+    is behind every glider after a second.  With the cubic-polynomial aerodynamics (the model of every reference driver) the
+    loop settles into the steady glide; the random-weight 4x128 surrogate has no physics to settle into, but stays bounded."""
     import torch
     from aircraft_amd.control import ILQR, QuadraticCost, RecedingHorizon
+    from aircraft_amd.synthetic import cruise_problem
 
     B, H = 1024, 50
-    ac = make_aircraft("nn", hidden=(128, 128, 128, 128))
-    cost = QuadraticCost.goal((30.0, 0.5), w_goal=1.0, height=-200.0, w_lateral_speed=0.5, r=0.5, reg=1.0)
-    il = ILQR(system=ac, dt=0.01, num_nodes=H, cost=cost, alphas=(1.0, 0.5, 0.1))
-    from aircraft_amd.synthetic import near_trim_problem
-    X0, _ = near_trim_problem(B, H, seed=11)
-    x0 = torch.from_numpy(np.ascontiguousarray(X0, dtype=np.float32)).to(gpu)
+    ac = make_aircraft("nn", hidden=(128, 128, 128, 128)) if model == "cfg3_4x128" else make_aircraft(model)
+    cost = QuadraticCost.cruise()
+    mk = lambda: ILQR(system=ac, dt=0.01, num_nodes=H, cost=cost, alphas=(1.0, 0.5, 0.1))  # noqa: E731
+    x0 = torch.from_numpy(np.ascontiguousarray(cruise_problem(B, seed=11), dtype=np.float32)).to(gpu)
     U0 = torch.zeros((H, 7, B), device=gpu)
-    eager = RecedingHorizon(il, overlap=30, iterations=2).allocate(x0, U0)
+    eager = RecedingHorizon(mk(), overlap=30, iterations=2).allocate(x0, U0)
     he = eager.run(20, record=True)
-    il2 = ILQR(system=ac, dt=0.01, num_nodes=H, cost=cost, alphas=(1.0, 0.5, 0.1))
-    graph = RecedingHorizon(il2, overlap=30, iterations=2).allocate(x0, U0).capture()
+    graph = RecedingHorizon(mk(), overlap=30, iterations=2).allocate(x0, U0).capture()
     hg = graph.run(20, record=True)
     assert he.shape == (20 * 20 + 1, 13, B)
-    assert torch.equal(he, hg) and torch.equal(eager.x0, graph.x0) and torch.equal(eager.U, graph.U)
-    # ... and the remaining 980 replays, keeping the executed states of every cycle on the device (1000 x 20 x 13 x 1024 fp32 = 1 GB)
+    bits = lambda t: t.contiguous().view(torch.int32)  # noqa: E731  (bit for bit)
+    assert torch.equal(bits(he), bits(hg)) and torch.equal(bits(eager.x0), bits(graph.x0)) and torch.equal(bits(eager.U), bits(graph.U))
+    # ... and the remaining 980 replays, the executed states of every cycle kept on the device (1000 x 20 x 13 x 1024 fp32 = 1 GB)
     rest = graph.run(980, record=True)
-    assert rest.shape == (980 * 20 + 1, 13, B) and torch.equal(rest[0], hg[-1])
+    assert rest.shape == (980 * 20 + 1, 13, B) and torch.equal(bits(rest[0]), bits(hg[-1]))
     hist = torch.cat([hg, rest[1:]])
+    del rest
     fin = torch.isfinite(hist).all(dim=1).all(dim=0)  # per instance
-    parity_report("cfg5_full_replay", instances=B, finite_instances=int(fin.sum()), solves=1000)
-    assert float(fin.float().mean()) >= 0.99, int(fin.sum())
-    h = hist[:, :, fin]
-    step = (h[1:, 0:3] - h[:-1, 0:3]).norm(dim=1)
-    speed = h[:-1, 3:6].norm(dim=1)
-    assert float((step - speed * 0.01).abs().max()) < 0.05   # continuity: one dt apart, never a jump
-    assert float((h[:, 6:10].norm(dim=1) - 1).abs().max()) < 1e-5
+    step = (hist[1:, 0:3] - hist[:-1, 0:3]).norm(dim=1)
+    speed = hist[:-1, 3:6].norm(dim=1)
+    jump = float((step - speed * 0.01).abs().max())
+    qerr = float((hist[:, 6:10].norm(dim=1) - 1).abs().max())
+    w_end = float(hist[-1, 10:13].norm(dim=0).max())
+    parity_report("cfg5_full_replay", model=model, instances=B, finite_instances=int(fin.sum()), solves=1000,
+                  worst_position_jump_m=jump, worst_quaternion_norm_error=qerr, worst_final_body_rate=w_end)
+    assert bool(fin.all()), int(fin.sum())
+    assert jump < 0.05     # continuity: consecutive executed states are one dt apart, never a jump
+    assert qerr < 1e-5
+    if model == "poly":    # the real aerodynamics settle into the steady glide (every instance the same one)
+        assert w_end < 0.05 and float(hist[-1, 3:6].norm(dim=0).std()) < 0.05
