@@ -43,6 +43,17 @@ def source_sha() -> str:
     return hh.hexdigest()[:16]
 
 
+def _deps(obj):
+    """Headers a translation unit really includes (the compiler's own -MMD list from the last build of this object), so a
+    change to one engine header rebuilds only the units built on it; all headers when no list exists yet."""
+    d = obj + ".d"
+    if not os.path.exists(d):
+        return HEADERS
+    txt = open(d).read().replace("\\\n", " ")
+    files = [f for f in txt.split(":", 1)[-1].split() if f.endswith((".hpp", ".h")) and "/opt/rocm" not in f and not f.startswith("/usr")]
+    return [f for f in files if os.path.exists(f)] or HEADERS
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -66,12 +77,12 @@ def _build(force, verbose, jobs, OBJ, OUT, CFLAGS) -> str:
     for src in sources():
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or _stale(obj, [src] + HEADERS + [os.path.abspath(__file__)]):
+        if force or _stale(obj, [src] + _deps(obj) + [os.path.abspath(__file__)]):
             todo.append((src, obj))
 
     def cc(job):
         src, obj = job
-        cmd = ["hipcc", *CFLAGS, *UNIT_FLAGS.get(os.path.basename(src)[:-4], []), "-c", src, "-o", obj]
+        cmd = ["hipcc", *CFLAGS, *UNIT_FLAGS.get(os.path.basename(src)[:-4], []), "-MMD", "-MF", obj + ".d", "-c", src, "-o", obj]
         if verbose:
             print("[aircraft_amd.build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

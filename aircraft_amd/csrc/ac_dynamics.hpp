@@ -7,6 +7,9 @@
 //   forces/moments                       dynamics/aircraft.py:309-330, dynamics/base.py:253-288
 //   state_derivative / RK4 / sub-steps   dynamics/base.py:290-480
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "ac_math.hpp"
 #include "../../include/aircraft_hip.h"
 
@@ -20,6 +23,10 @@ struct DevParams {
     float poly_coef[6 * 34];
     float poly_intercept[6];
     float mlp_in_mean[5], mlp_in_std[5], mlp_out_mean[6], mlp_out_std[6];
+    // mlp_out_std[k] / mlp_in_std[j], rounded once on the host (IEEE single division, what the device computes too): the
+    // chain rule dC_k = sum_j J[k][j] * jscale[k][j] * d(in_j) reads them as scalar operands instead of holding thirty
+    // wave-uniform quotients in vector registers for the life of the kernel
+    float mlp_jscale[6][5];
 };
 
 constexpr float kDeg = 0.017453292519943295f;  // pi/180
@@ -245,6 +252,12 @@ template <class T> AC_DI void rigid_body(const DevParams& P, const T x[13], cons
     for (int i = 0; i < 3; ++i) xd[10 + i] = Ii[3 * i] * rhs[0] + Ii[3 * i + 1] * rhs[1] + Ii[3 * i + 2] * rhs[2];
 }
 
+// A coefficient provider whose prefetch() has already formed the aerodynamic quantities of this x hands them over through
+// kept_aero(a) (MlpLazyCoeffs, ac_mlp_valu.hpp); every other provider has no such member and f forms them itself.
+template <class C, class A, class = void> struct keeps_aero : std::false_type {};
+template <class C, class A>
+struct keeps_aero<C, A, std::void_t<decltype(std::declval<C&>().kept_aero(std::declval<A&>()))>> : std::true_type {};
+
 // x_dot = f(x, u).  coeffs.prefetch(P, x, u-values) must have been called for this x.
 template <class T, class Coeffs>
 AC_DI void state_derivative(const DevParams& P, Coeffs& coeffs, const T x[13], const T u[7], T xd[13]) {
@@ -253,7 +266,8 @@ AC_DI void state_derivative(const DevParams& P, Coeffs& coeffs, const T x[13], c
         quad_forces(P, u, o);
     } else {
         AeroPre<T> a;
-        aero_pre(P, x, a);
+        if constexpr (keeps_aero<Coeffs, AeroPre<T>>::value) coeffs.kept_aero(a);  // formed by prefetch() already
+        else aero_pre(P, x, a);
         T C[6];
         coeffs(P, a, x, u, C);
         aero_post(P, a, u, C, o);
@@ -377,8 +391,12 @@ AC_DI void rk4_step_seeded(const DevParams& P, Coeffs& coeffs, int g, const floa
     typedef Dual<N> T;
     typedef SeedsT<N> Seeds;
     T acc[13], xs[13], k[13];
+    {
+        int g0 = g;
+        asm volatile("" : "+v"(g0));  // (likewise: not hoisted out of an enclosing sub-step / unit-group loop)
 #pragma unroll
-    for (int i = 0; i < 13; ++i) { xs[i] = Seeds::state(g, i, xv[i]); acc[i] = T(0.f); }
+        for (int i = 0; i < 13; ++i) { xs[i] = Seeds::state(g0, i, xv[i]); acc[i] = T(0.f); }
+    }
 #pragma nounroll
     for (int s = 0; s < 4; ++s) {
         coeffs.prefetch(P, xs, uv);
@@ -398,9 +416,11 @@ AC_DI void rk4_step_seeded(const DevParams& P, Coeffs& coeffs, int g, const floa
             xs[i] = Seeds::state(gg, i, xv[i]) + hs * k[i];
         }
     }
-    const T h6 = Seeds::step(g, hv * (1.0f / 6.0f), dh_ddt * (1.0f / 6.0f));
+    int ge = g;
+    asm volatile("" : "+v"(ge));  // the seeds of the final combination are rebuilt here, not carried across the four stages
+    const T h6 = Seeds::step(ge, hv * (1.0f / 6.0f), dh_ddt * (1.0f / 6.0f));
 #pragma unroll
-    for (int i = 0; i < 13; ++i) xo[i] = Seeds::state(g, i, xv[i]) + h6 * acc[i];
+    for (int i = 0; i < 13; ++i) xo[i] = Seeds::state(ge, i, xv[i]) + h6 * acc[i];
 }
 
 }  // namespace ac

@@ -37,9 +37,11 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_step_sens(const DevParams P, c
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MlpEngine<6, WT, USE_MFMA> eng(plan, blob, smem);
     eng.st.start();
+    WaveClock wc;
+    wc.start();
     eng.load_weights();
     AC_MARK(eng.st, 0);  // [0] prologue: weights into LDS
-#ifdef AC_STAMPS
+#if defined(AC_STAMPS) || defined(AC_CLOCKS)
     unsigned long long* stamp_buf = reinterpret_cast<unsigned long long*>(c);
     c = nullptr;
 #endif
@@ -65,6 +67,9 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_step_sens(const DevParams P, c
     AC_MARK(eng.st, 8);  // [8] stores
 #ifdef AC_STAMPS
     eng.st.flush(stamp_buf);
+#endif
+#ifdef AC_CLOCKS
+    wc.stop(stamp_buf);
 #endif
 }
 

@@ -62,6 +62,30 @@ struct Stamper {
 #define AC_MARK(st, id) ((void)0)
 #endif
 
+// -DAC_CLOCKS (a measurement flavour, tools/diag_clock_ratio.py): every wave adds its lifetime in shader-clock cycles
+// (s_memtime) and in constant 100 MHz ticks (s_memrealtime) to buf[0], buf[1] and counts itself in buf[2] — the clock the
+// chip really holds under THIS kernel is 100 MHz x buf[0] / buf[1] (power management lowers it under heavy vector load).
+struct WaveClock {
+#ifdef AC_CLOCKS
+    unsigned long long t0, r0;
+    __device__ __forceinline__ void start() { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    __device__ __forceinline__ void stop(unsigned long long* buf) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if ((threadIdx.x & 63) == 0 && buf) {
+            atomicAdd(&buf[0], t1 - t0); atomicAdd(&buf[1], r1 - r0); atomicAdd(&buf[2], 1ull);
+            atomicMax(&buf[3], r1 - r0);          // longest wave lifetime (100 MHz ticks)
+            atomicMin(&buf[4], r0); atomicMax(&buf[5], r1);  // first start / last end of any wave since the buffer was reset
+            unsigned xcc;                          // per-XCD lifetime sums: does one die run slower than the others?
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            atomicAdd(&buf[8 + (xcc & 7)], r1 - r0);
+        }
+    }
+#else
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void stop(unsigned long long*) {}
+#endif
+};
+
 template <int N> AC_DI Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) {
     Dual<N> r; r.v = a.v + b.v;
 #pragma unroll

@@ -1252,7 +1252,7 @@ template <class Engine> struct MlpCoeffs {
             for (int i = 0; i < N; ++i) {
                 float s = 0.f;
 #pragma unroll
-                for (int j = 0; j < 5; ++j) s = fmaf(J[k][j] * (P.mlp_out_std[k] / P.mlp_in_std[j]), in[j].d[i], s);
+                for (int j = 0; j < 5; ++j) s = fmaf(J[k][j] * P.mlp_jscale[k][j], in[j].d[i], s);
                 C[k].d[i] = s;
             }
         }
@@ -1325,7 +1325,7 @@ template <class Engine, int TOFF> struct MlpPairCoeffs {
             for (int i = 0; i < N; ++i) {
                 float s = 0.f;
 #pragma unroll
-                for (int j = 0; j < 5; ++j) s = fmaf(J[k][j] * (P.mlp_out_std[k] / P.mlp_in_std[j]), in[j].d[i], s);
+                for (int j = 0; j < 5; ++j) s = fmaf(J[k][j] * P.mlp_jscale[k][j], in[j].d[i], s);
                 C[k].d[i] = s;
             }
         }

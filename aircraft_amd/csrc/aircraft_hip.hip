@@ -2,6 +2,7 @@
 // gfx950 only.  No allocation or synchronisation inside the compute entry points (graph-capturable).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -80,6 +81,7 @@ struct ac_handle {
     ValuPlan vplan;
     int vwidth;        // 32 or 64
     float* d_vblob;    // weight image [layer][K][N] (+ biases), device
+    unsigned* d_queue; // ticket counter of the persistent tiled kernels (GroupQueue, ac_mlp_valu.hpp); 0 between launches
     float* d_hess_ws;  // [n][4][126] stage tensors of the MLP Hessian path (ac_reserve_hess_workspace)
     size_t hess_ws_floats;
     float* d_hess_ws2;  // sub-step composition of the second-order blocks (substeps > 1)
@@ -240,9 +242,14 @@ int ac_create(const ac_params* params, ac_handle** out) {
         h->all_pair = ea && ea[0] == '1';
     }
 #endif
-#ifdef AC_STAMPS
-    h->no_pair = true;  // the diagnostic flavor passes its stamp buffer through `c`; only k_nn_step_sens knows that
+#if defined(AC_STAMPS) || defined(AC_CLOCKS)
+    h->no_pair = true;  // the diagnostic flavours pass their buffer through `c`; only k_nn_step_sens knows that
 #endif
+    {   // ticket counter of the persistent kernels' work queue: zero now, and left at zero by every launch that uses it
+        hipError_t e = hipMalloc(&h->d_queue, 256);
+        if (e == hipSuccess) e = hipMemset(h->d_queue, 0, 256);
+        if (e != hipSuccess) { if (h->d_queue) (void)hipFree(h->d_queue); delete h; return hip_fail(e, "hipMalloc(work queue)"); }
+    }
     *out = h;
     return AC_OK;
 }
@@ -252,6 +259,7 @@ int ac_destroy(ac_handle* h) {
     if (!h) return AC_ERR_BAD_ARG;
     if (h->d_blob) (void)hipFree(h->d_blob);
     if (h->d_vblob) (void)hipFree(h->d_vblob);
+    if (h->d_queue) (void)hipFree(h->d_queue);
     if (h->d_track) (void)hipFree(h->d_track);
     if (h->d_hess_ws) (void)hipFree(h->d_hess_ws);
     if (h->d_hess_ws2) (void)hipFree(h->d_hess_ws2);
@@ -504,6 +512,8 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
     memcpy(h->dp.mlp_in_std, in_std, 5 * sizeof(float));
     memcpy(h->dp.mlp_out_mean, out_mean, 6 * sizeof(float));
     memcpy(h->dp.mlp_out_std, out_std, 6 * sizeof(float));
+    for (int k = 0; k < 6; ++k)
+        for (int j = 0; j < 5; ++j) h->dp.mlp_jscale[k][j] = out_std[k] / in_std[j];  // float / float: one IEEE rounding
     h->has_mlp = true;
     return AC_OK;
 }
@@ -754,22 +764,26 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
         // rounds over the CUs.  A remainder of at most half a round is given to k_nn_step_sens_pair (two waves per 16
         // units, 32 units per workgroup, ~0.73 of a full workgroup's time) instead of paying a full round for it.
         if (!h->use_mfma && h->has_vplan) {
-            // "MFMA off": the tiled v_pk_fma_f32 engine (ac_mlp_valu.hpp), 16 units per wave, 64 per workgroup
-            const int grid = (int)((n + 63) / 64);
-            const int lds = h->vplan.image_floats * 4 + 4 * 96 * (h->vwidth + 4) * 4;
+            // "MFMA off": the tiled v_pk_fma_f32 engine (ac_mlp_valu.hpp)
             bool launched = false;
+            // 8 units per wave, eight waves per workgroup (two per SIMD), persistent: at most one workgroup per CU
+            const long cus_t = h->num_cus > 0 ? h->num_cus : 256;
+            // (a batch smaller than the chip fills whole workgroups: 200 full ones ran cfg2's 12 800 units in 0.120 ms, 256 of
+            // six or seven working waves in 0.135)
+            const int grid = (int)std::min<long>((n + 63) / 64, cus_t);
+            const int lds = h->vplan.image_floats * 4 + 8 * 48 * (h->vwidth + 4) * 4;
 #define AC_TILED_SENS(W_)                                                                                          \
             if (h->vwidth == W_) {                                                                                 \
-                auto kern = k_nn_step_sens_tiled<W_>;                                                              \
+                auto kern = k_nn_step_sens_tiled8<W_>;                                                             \
                 int rc_ = set_lds_limit(h, kern, lds);                                                             \
                 if (rc_ != AC_OK) return rc_;                                                                      \
-                hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->vplan, h->d_vblob, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c); \
+                hipLaunchKernelGGL(kern, grid, kBlock8, lds, st, h->dp, h->vplan, h->d_vblob, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c, h->d_queue); \
                 launched = true;                                                                                   \
             }
             AC_TILED_SENS(32) AC_TILED_SENS(64)
 #undef AC_TILED_SENS
             if (!launched) return fail(AC_ERR_UNSUPPORTED, "no tiled vector-ALU kernel instance for this hidden width");
-            note_launch(h, "k_nn_step_sens_tiled", grid, kBlock, lds);
+            note_launch(h, "k_nn_step_sens_tiled8", grid, kBlock8, lds);
             AC_HIP(hipGetLastError());
             return AC_OK;
         }
@@ -848,21 +862,22 @@ static int deriv_sens_impl(ac_handle* h, const float* X, const float* U, long n,
     if (rc != AC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (h->dp.p.model_kind == AC_MODEL_NN && !h->use_mfma && h->has_vplan) {
-        const int grid = (int)((n + 63) / 64);
-        const int lds = h->vplan.image_floats * 4 + 4 * 96 * (h->vwidth + 4) * 4;
+        const long cus_t = h->num_cus > 0 ? h->num_cus : 256;
+        const int grid = (int)std::min<long>((n + 63) / 64, cus_t);  // persistent workgroups + work queue (GroupQueue, ac_mlp_valu.hpp)
+        const int lds = h->vplan.image_floats * 4 + 8 * 48 * (h->vwidth + 4) * 4;
         bool launched = false;
 #define AC_TILED_DS(W_)                                                                                            \
         if (h->vwidth == W_) {                                                                                     \
-            auto kern = k_nn_deriv_sens_tiled<W_>;                                                                 \
+            auto kern = k_nn_deriv_sens_tiled8<W_>;                                                                \
             int rc_ = set_lds_limit(h, kern, lds);                                                                 \
             if (rc_ != AC_OK) return rc_;                                                                          \
-            hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->vplan, h->d_vblob, X, U, n, blk, Xdot, Fx, Fu); \
+            hipLaunchKernelGGL(kern, grid, kBlock8, lds, st, h->dp, h->vplan, h->d_vblob, X, U, n, blk, Xdot, Fx, Fu, h->d_queue); \
             launched = true;                                                                                       \
         }
         AC_TILED_DS(32) AC_TILED_DS(64)
 #undef AC_TILED_DS
         if (!launched) return fail(AC_ERR_UNSUPPORTED, "no tiled vector-ALU kernel instance for this hidden width");
-        note_launch(h, "k_nn_deriv_sens_tiled", grid, kBlock, lds);
+        note_launch(h, "k_nn_deriv_sens_tiled8", grid, kBlock8, lds);
         AC_HIP(hipGetLastError());
         return AC_OK;
     }

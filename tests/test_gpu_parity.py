@@ -397,7 +397,7 @@ def test_valu_tiled_engine_step_sens(gpu, hidden, substeps):
     X, U = synthetic_units(n, seed=37, flaps=True)
     dt = f32_exact(np.random.default_rng(2).uniform(4e-3, 1e-2, n)) * (10 if substeps == 10 else 1)
     Xn, A, Bm, c = ac.step_sens(dev(X, gpu), dev(U, gpu), dev(dt, gpu))
-    assert ac.last_launch()[0] == "k_nn_step_sens_tiled"
+    assert ac.last_launch()[0].startswith("k_nn_step_sens_tiled")
     Xr, Ar, Br, cr = make_oracle(ac).step_sens(X, U, dt)
     if substeps == 1:
         assert block_rel_err(Xn.cpu().numpy(), Xr) < STATE_TOL
@@ -408,5 +408,7 @@ def test_valu_tiled_engine_step_sens(gpu, hidden, substeps):
     m = make_aircraft("nn", use_mfma=True, **kw)
     Xm, Am, Bmm, cm = m.step_sens(dev(X, gpu), dev(U, gpu), dev(dt, gpu))
     if substeps == 1:
-        assert block_rel_err(Xn.cpu().numpy(), Xm.cpu().numpy()) < 2e-6
+        # (the two flavours round differently in a few places — this one takes the network inputs from the value parts of
+        # the dual aerodynamic quantities, the matrix-core one from a primal pass: a few ulps, far inside the 1e-5 bar)
+        assert block_rel_err(Xn.cpu().numpy(), Xm.cpu().numpy()) < 5e-6
         assert unit_max_rel(A.cpu().numpy(), Am.cpu().numpy()).max() < 1e-5

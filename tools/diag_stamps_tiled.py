@@ -23,14 +23,16 @@ for _ in range(2):
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); ms.linearise(X, U, out=(F, A, Bm, stamps)); e1.record(); torch.cuda.synchronize()
-assert ac.last_launch()[0] == "k_nn_step_sens_tiled"
+name = ac.last_launch()[0]
+assert name.startswith("k_nn_step_sens_tiled")
+upw = 8 if name.endswith("8") else 16
 s = stamps.cpu().numpy().astype(np.float64)
 nw = s[12]
 names = {0: "prologue (36 KB weight image -> LDS, barrier)", 1: "between forward() calls: dual rigid body + primal aero + z",
          3: "operand rows of layer 0 written", 2: "layer 0 (K = 8) + epilogue", 4: "hidden layers (2 x 16 k-steps + epilogues)",
          5: "last layer (64 -> 6) + epilogue", 6: "outputs y, J read back", 7: "after the last stage: dual rigid body + RK4 combine"}
 tot = s[:12].sum()
-print(f"B={B}: kernel {e0.elapsed_time(e1):.3f} ms ; waves {int(nw)} ; mean cycles per wave {tot / nw:.0f}")
-print("  ideal hidden layers: 2 x 3072 v_pk_fma_f32 per stage; 27.6 k per wave and step")
+print(f"B={B}: {name} {e0.elapsed_time(e1):.3f} ms ; waves {int(nw)} ({upw} units each) ; mean cycles per wave {tot / nw:.0f}")
+print(f"  ideal hidden layers: 2 x {3072 * upw // 16} v_pk_fma_f32 per stage; {27.6 * upw / 16:.1f} k per wave and step")
 for i in (0, 1, 3, 2, 4, 5, 6, 7):
     print(f"  [{i}] {names[i]:62s} {s[i] / nw:10.0f} cyc/wave  {100 * s[i] / tot:5.1f} %")
