@@ -25,6 +25,11 @@ struct WaveUnit {
     AC_DI WaveUnit(long n, long blk, long unit0 = 0)
         : lane(threadIdx.x & 63), col(threadIdx.x & 15), g((threadIdx.x & 63) >> 4),
           unit(raw_unit(unit0) < n ? raw_unit(unit0) : n - 1), live(raw_unit(unit0) < n), ua(unit, blk) {}
+    // task `task` (64 units: one workgroup's share) of a persistent grid; `tid` is the caller's laundered threadIdx.x
+    AC_DI static long task_unit(int tid, long task) { return task * 64 + (tid >> 6) * 16 + (tid & 15); }
+    AC_DI WaveUnit(int tid, long task, long n, long blk)
+        : lane(tid & 63), col(tid & 15), g((tid & 63) >> 4),
+          unit(task_unit(tid, task) < n ? task_unit(tid, task) : n - 1), live(task_unit(tid, task) < n), ua(unit, blk) {}
 };
 
 template <int WT, bool USE_MFMA>
@@ -45,25 +50,37 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_step_sens(const DevParams P, c
     unsigned long long* stamp_buf = reinterpret_cast<unsigned long long*>(c);
     c = nullptr;
 #endif
-    const WaveUnit w(n, blk);
-    float xv[13], uv[7];
-    load_rows<13>(X, w.ua, xv);
-    load_rows<7>(U, w.ua, uv);
-    const float hv = dt_per_unit ? dt_per_unit[w.unit] : dt;
-    Dual<4> x[13];
     MlpCoeffs<MlpEngine<6, WT, USE_MFMA>> coeffs(eng);
-    sens_update<4>(P, coeffs, w.g, w.col, w.ua, xv, uv, hv, x, A, Bm, c, w.live);
-    eng.drain();
-    AC_MARK(eng.st, 7);  // [7] dual aero + rigid body + RK4 combine (everything outside forward())
-    if (w.live) {
-        const UnitAddr uo = w.ua.late();
-        if (w.g == 0) {
-            float* p = Xn + uo.off(13);
+    // PERSISTENT workgroups: the grid is at most one workgroup per CU and workgroup b runs the tasks (64 units each)
+    // b, b + gridDim.x, ...  With one 138 KB workgroup resident per CU, a workgroup per task had every CU idle between the
+    // last wave of one task and the first of the next (dispatch + the weight prologue: -DAC_CLOCKS measured a wave lifetime
+    // of 303 us inside rounds of 320); here the next task's input loads follow the previous task's stores directly and the
+    // weights are loaded once.  The four waves stay in step through the barriers of the streamed layers, every wave runs the
+    // same number of tasks, and the loop bounds are workgroup-uniform: the grid drains by itself.
+    const long ntasks = (n + 63) / 64;
+#pragma nounroll
+    for (long task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));  // lane-dependent values are rebuilt per task, not hoisted into registers the body needs
+        const WaveUnit w(tid, task, n, blk);
+        float xv[13], uv[7];
+        load_rows<13>(X, w.ua, xv);
+        load_rows<7>(U, w.ua, uv);
+        const float hv = dt_per_unit ? dt_per_unit[w.unit] : dt;
+        Dual<4> x[13];
+        sens_update<4>(P, coeffs, w.g, w.col, w.ua, xv, uv, hv, x, A, Bm, c, w.live);
+        AC_MARK(eng.st, 7);  // [7] dual aero + rigid body + RK4 combine (everything outside forward())
+        if (w.live) {
+            const UnitAddr uo = w.ua.late();
+            if (w.g == 0) {
+                float* p = Xn + uo.off(13);
 #pragma unroll
-            for (int i = 0; i < 13; ++i) p[(long)i * blk] = x[i].v;
+                for (int i = 0; i < 13; ++i) p[(long)i * blk] = x[i].v;
+            }
+            SensIO::store(w.g, uo, x, A, Bm, c, true);
         }
-        SensIO::store(w.g, uo, x, A, Bm, c, true);
     }
+    eng.drain();
     AC_MARK(eng.st, 8);  // [8] stores
 #ifdef AC_STAMPS
     eng.st.flush(stamp_buf);

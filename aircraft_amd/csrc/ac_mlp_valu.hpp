@@ -282,22 +282,29 @@ template <int WIDTH> struct MlpEngineTiled {
 //     two operand banks, everything a step consumes requested one step earlier — with the sister wave of the SIMD
 //     covering what is left of the LDS latency;
 //   * LDS: the 36 KB weight image once per workgroup + 8 x 48 x 68 x 4 B = 138 KB, one 8-wave workgroup per CU.
-template <int WIDTH> struct MlpEngineTiled8 {
+// SL = 6: value + five input tangents per unit (the sensitivity kernels).  SL = 1: the value row alone — the sequential
+// rollout of small batches, where what counts is the latency of one network evaluation: 8 instances per wave put a batch
+// of 256 on 32 waves with a sixth of the 64-instances-per-wave tile's instructions per evaluation.
+// KU: units per wave (8; 4 for the width-64 rollout: 16 lanes per instance halve the instructions of an evaluation again).
+template <int WIDTH, int SL = 6, int KU = 8> struct MlpEngineTiled8 {
     static_assert(WIDTH == 32 || WIDTH == 64, "hidden width padded to 32 or 64");
-    static constexpr bool kTangent = true;
-    static constexpr int kTangents = 5;
-    static constexpr int kUnits = 8;               // units per wave
+    static_assert(SL == 6 || SL == 1, "value + five tangents, or the value row alone");
+    static constexpr bool kTangent = SL > 1;
+    static constexpr int kTangents = SL - 1;
+    static_assert(KU == 8 || (KU == 4 && WIDTH == 64 && SL == 1), "a lane owns whole groups of four neurons");
+    static constexpr int kUnits = KU;              // units per wave
+    static constexpr int LPU = 64 / KU;            // lanes per unit
     static constexpr int S = WIDTH + 4;            // activation row stride in floats
-    static constexpr int kRows = 6 * kUnits;
+    static constexpr int kRows = SL * kUnits;
     static constexpr int kBufFloats = kRows * S;
     static constexpr int kWaves = 8;
-    static constexpr int NQ = WIDTH / 32;          // 16-byte neuron groups per lane
+    static constexpr int NQ = WIDTH / (4 * LPU);   // 16-byte neuron groups per lane
     static constexpr int NP = 2 * NQ;              // ... as packed pairs
     static constexpr int NB = 4 * NQ;              // neurons per lane
 
     const ValuPlan& plan;
     const float* wimg;   // LDS: weight image
-    float* act;          // LDS: this wave's activation buffer [6 slabs][8 units][S]
+    float* act;          // LDS: this wave's activation buffer [SL slabs][8 units][S]
     const float* gimg;
     char* lds0;
     int lane, unit, tj;
@@ -306,7 +313,7 @@ template <int WIDTH> struct MlpEngineTiled8 {
     static AC_DI int lds_bytes(const ValuPlan& pl) { return pl.image_floats * 4 + kWaves * kBufFloats * 4; }
 
     AC_DI MlpEngineTiled8(const ValuPlan& pl, const float* blob, char* lds_base) : plan(pl) {
-        lane = threadIdx.x & 63; unit = lane & 7; tj = lane >> 3;
+        lane = threadIdx.x & 63; unit = lane % KU; tj = lane / KU;
         wimg = reinterpret_cast<const float*>(lds_base);
         act = reinterpret_cast<float*>(lds_base) + pl.image_floats + (threadIdx.x >> 6) * kBufFloats;
         gimg = blob;
@@ -323,7 +330,7 @@ template <int WIDTH> struct MlpEngineTiled8 {
         __builtin_amdgcn_wave_barrier();
     }
     AC_DI int row_of(int s) const { return s * kUnits + unit; }
-    AC_DI int ncol(int h) const { return 4 * tj + 32 * h; }  // first neuron of this lane's h-th group
+    AC_DI int ncol(int h) const { return 4 * tj + 4 * LPU * h; }  // first neuron of this lane's h-th group
 
     AC_DI void load_w(f32x4 (&wv)[2][NQ], const float* __restrict__ w, int k0) const {
 #pragma unroll
@@ -331,16 +338,16 @@ template <int WIDTH> struct MlpEngineTiled8 {
 #pragma unroll
             for (int h = 0; h < NQ; ++h) wv[kk][h] = *reinterpret_cast<const f32x4*>(w + (k0 + kk) * WIDTH + ncol(h));
     }
-    AC_DI void load_a(f32x2 (&a)[6], int k0) const {
+    AC_DI void load_a(f32x2 (&a)[SL], int k0) const {
 #pragma unroll
-        for (int s = 0; s < 6; ++s) a[s] = *reinterpret_cast<const f32x2*>(act + row_of(s) * S + k0);
+        for (int s = 0; s < SL; ++s) a[s] = *reinterpret_cast<const f32x2*>(act + row_of(s) * S + k0);
     }
     // acc[6 rows][NP neuron pairs] (+)= A[rows][k0, k0 + 1] * W[k0, k0 + 1][this lane's neurons]; FIRST: the step that starts
     // the accumulators (a multiply instead of 48 zero-fills and the first 48 adds: same values, 0 + a w = a w)
     template <bool FIRST = false>
-    AC_DI void step(f32x2 (&acc)[6][NP], const f32x2 (&a)[6], const f32x4 (&wv)[2][NQ]) const {
+    AC_DI void step(f32x2 (&acc)[SL][NP], const f32x2 (&a)[SL], const f32x4 (&wv)[2][NQ]) const {
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {
+        for (int s = 0; s < SL; ++s) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -355,7 +362,7 @@ template <int WIDTH> struct MlpEngineTiled8 {
 
     // bias + tanh on the value row, (1 - h^2) on the five tangent rows of the same unit — all in this lane — then the 6 x NB
     // results go back to the activation buffer as the next layer's operand
-    template <bool TANH> AC_DI void epilogue_store(f32x2 (&acc)[6][NP], const float* __restrict__ bias) {
+    template <bool TANH> AC_DI void epilogue_store(f32x2 (&acc)[SL][NP], const float* __restrict__ bias) {
 #pragma unroll
         for (int h = 0; h < NQ; ++h) {
             const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + ncol(h));
@@ -367,7 +374,7 @@ template <int WIDTH> struct MlpEngineTiled8 {
                     const float hv = act_tanh(v), sp = fmaf(-hv, hv, 1.0f);
                     acc[0][p][x] = hv;
 #pragma unroll
-                    for (int s = 1; s < 6; ++s) acc[s][p][x] *= sp;
+                    for (int s = 1; s < SL; ++s) acc[s][p][x] *= sp;
                 } else {
                     acc[0][p][x] = v;
                 }
@@ -375,7 +382,7 @@ template <int WIDTH> struct MlpEngineTiled8 {
         }
         wave_sync();  // every lane is done reading this layer's operand rows before they are overwritten
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {
+        for (int s = 0; s < SL; ++s) {
             float* dst = act + row_of(s) * S;
 #pragma unroll
             for (int h = 0; h < NQ; ++h)
@@ -385,11 +392,52 @@ template <int WIDTH> struct MlpEngineTiled8 {
         wave_sync();
     }
 
+    // SL = 1 (the rollout of small batches): one row per lane makes a 2-deep step four packed FMAs — far shorter than an LDS
+    // round trip, so the pipeline below would stall at every step (measured: 4.7 us per network evaluation).  Here the lane's
+    // whole operand row is fetched at once and the weights stream in 8-deep chunks, two in flight.
+    AC_DI void dense_layer_row(int l) {
+        static_assert(SL == 1 || SL == 6, "");
+        const float* w = wimg + plan.w_off[l];
+        f32x4 arow[WIDTH / 4];
+#pragma unroll
+        for (int i = 0; i < WIDTH / 4; ++i) arow[i] = *reinterpret_cast<const f32x4*>(act + row_of(0) * S + 4 * i);
+        f32x4 wc[2][8][NQ];
+        auto fetchw = [&](int b, int k0) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int h = 0; h < NQ; ++h) wc[b][kk][h] = *reinterpret_cast<const f32x4*>(w + (k0 + kk) * WIDTH + ncol(h));
+        };
+        f32x2 acc[1][NP];
+        fetchw(0, 0);
+#pragma unroll
+        for (int k0 = 0; k0 < WIDTH; k0 += 8) {
+            const int b = (k0 >> 3) & 1;
+            if (k0 + 8 < WIDTH) fetchw(b ^ 1, k0 + 8);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int k = k0 + kk;
+                const f32x2 ap = {arow[k >> 2][2 * ((k >> 1) & 1)], arow[k >> 2][2 * ((k >> 1) & 1) + 1]};
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const f32x2 wp = {wc[b][kk][p >> 1][2 * (p & 1)], wc[b][kk][p >> 1][2 * (p & 1) + 1]};
+                    if (k == 0) pk_mul_alo(acc[0][p], ap, wp);
+                    else if ((k & 1) == 0) pk_fma_alo(acc[0][p], ap, wp);
+                    else pk_fma_ahi(acc[0][p], ap, wp);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        epilogue_store<true>(reinterpret_cast<f32x2 (&)[SL][NP]>(acc), wimg + plan.b_off[l]);
+    }
+
     AC_DI void dense_layer(int l) {
-        f32x2 acc[6][NP];
+        if constexpr (SL == 1) { dense_layer_row(l); return; }
+        f32x2 acc[SL][NP];
         const float* w = wimg + plan.w_off[l];
         f32x4 wA[2][NQ], wB[2][NQ];
-        f32x2 aA[6], aB[6];
+        f32x2 aA[SL], aB[SL];
         load_w(wA, w, 0); load_a(aA, 0);
         // steps 0 and 2 peeled: the first one starts the accumulators
         load_w(wB, w, 2); load_a(aB, 2);
@@ -419,7 +467,7 @@ template <int WIDTH> struct MlpEngineTiled8 {
     // per neuron in the tile's own order, tangent row s = row s - 1 of W0.  z is this lane's own unit's: no shuffle.
     AC_DI void first_layer_direct(const float z[5]) {
         const float* w = wimg + plan.w_off[0];
-        f32x2 acc[6][NP];
+        f32x2 acc[SL][NP];
 #pragma unroll
         for (int h = 0; h < NQ; ++h) {
             f32x4 wr[5];
@@ -433,7 +481,7 @@ template <int WIDTH> struct MlpEngineTiled8 {
                 for (int k = 1; k < 5; ++k) v = fmaf(z[k], wr[k][e], v);
                 acc[0][p][x] = v;
 #pragma unroll
-                for (int sl = 1; sl < 6; ++sl) acc[sl][p][x] = wr[sl - 1][e];
+                for (int sl = 1; sl < SL; ++sl) acc[sl][p][x] = wr[sl - 1][e];
             }
         }
         epilogue_store<true>(acc, wimg + plan.b_off[0]);
@@ -444,19 +492,39 @@ template <int WIDTH> struct MlpEngineTiled8 {
     // software-pipelined like the dense layers; the 6 x 8 results then cross to all eight lanes of the unit through the
     // buffer (columns 0..7 of the unit's rows).
     AC_DI void last_layer(int l) {
-        const float* wt = wimg + plan.w_off[l] + tj * (WIDTH + 4);
-        f32x2 acc[6];
+        const float* wt = wimg + plan.w_off[l] + (tj & 7) * (WIDTH + 4);  // (16 lanes per unit: lanes 8..15 shadow 0..7)
+        if constexpr (SL == 1) {  // one row: fetch it and the lane's weight row whole, then WIDTH / 2 packed FMAs (same order)
+            f32x4 ra1[WIDTH / 4], rw1[WIDTH / 4];
 #pragma unroll
-        for (int s = 0; s < 6; ++s) acc[s] = f32x2{0.f, 0.f};
-        f32x4 ra[2][6], rw[2];
+            for (int i = 0; i < WIDTH / 4; ++i) {
+                ra1[i] = *reinterpret_cast<const f32x4*>(act + row_of(0) * S + 4 * i);
+                rw1[i] = *reinterpret_cast<const f32x4*>(wt + 4 * i);
+            }
+            f32x2 a1 = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < WIDTH / 4; ++i) {
+                pk_fma_pair(a1, f32x2{ra1[i][0], ra1[i][1]}, f32x2{rw1[i][0], rw1[i][1]});
+                pk_fma_pair(a1, f32x2{ra1[i][2], ra1[i][3]}, f32x2{rw1[i][2], rw1[i][3]});
+            }
+            const float v = a1[0] + a1[1] + wimg[plan.b_off[l] + (tj & 7)];
+            const float o1 = plan.act_last ? act_tanh(v) : v;
+            wave_sync();
+            if (tj < 8) act[row_of(0) * S + tj] = o1;
+            wave_sync();
+            return;
+        }
+        f32x2 acc[SL];
+#pragma unroll
+        for (int s = 0; s < SL; ++s) acc[s] = f32x2{0.f, 0.f};
+        f32x4 ra[2][SL], rw[2];
         auto fetch = [&](int b, int k0) {
             rw[b] = *reinterpret_cast<const f32x4*>(wt + k0);
 #pragma unroll
-            for (int s = 0; s < 6; ++s) ra[b][s] = *reinterpret_cast<const f32x4*>(act + row_of(s) * S + k0);
+            for (int s = 0; s < SL; ++s) ra[b][s] = *reinterpret_cast<const f32x4*>(act + row_of(s) * S + k0);
         };
         auto compute = [&](int b) {
 #pragma unroll
-            for (int s = 0; s < 6; ++s) {
+            for (int s = 0; s < SL; ++s) {
                 pk_fma_pair(acc[s], f32x2{ra[b][s][0], ra[b][s][1]}, f32x2{rw[b][0], rw[b][1]});
                 pk_fma_pair(acc[s], f32x2{ra[b][s][2], ra[b][s][3]}, f32x2{rw[b][2], rw[b][3]});
             }
@@ -474,23 +542,23 @@ template <int WIDTH> struct MlpEngineTiled8 {
             __builtin_amdgcn_sched_barrier(0);
         }
         const float bj = wimg[plan.b_off[l] + tj];
-        float o[6];
+        float o[SL];
 #pragma unroll
-        for (int s = 0; s < 6; ++s) o[s] = acc[s][0] + acc[s][1];
+        for (int s = 0; s < SL; ++s) o[s] = acc[s][0] + acc[s][1];
         {
             const float v = o[0] + bj;
             if (plan.act_last) {
                 const float hv = act_tanh(v), sp = fmaf(-hv, hv, 1.0f);
                 o[0] = hv;
 #pragma unroll
-                for (int s = 1; s < 6; ++s) o[s] *= sp;
+                for (int s = 1; s < SL; ++s) o[s] *= sp;
             } else {
                 o[0] = v;
             }
         }
         wave_sync();
 #pragma unroll
-        for (int s = 0; s < 6; ++s) act[row_of(s) * S + tj] = o[s];
+        for (int s = 0; s < SL; ++s) act[row_of(s) * S + tj] = o[s];
         wave_sync();
     }
 
@@ -501,7 +569,7 @@ template <int WIDTH> struct MlpEngineTiled8 {
         const f32x4 y0 = *reinterpret_cast<const f32x4*>(act + row_of(0) * S), y1 = *reinterpret_cast<const f32x4*>(act + row_of(0) * S + 4);
         y[0] = y0[0]; y[1] = y0[1]; y[2] = y0[2]; y[3] = y0[3]; y[4] = y1[0]; y[5] = y1[1];
 #pragma unroll
-        for (int s = 1; s < 6; ++s) {
+        for (int s = 1; s < SL; ++s) {
             const f32x4 j0 = *reinterpret_cast<const f32x4*>(act + row_of(s) * S), j1 = *reinterpret_cast<const f32x4*>(act + row_of(s) * S + 4);
             J[0][s - 1] = j0[0]; J[1][s - 1] = j0[1]; J[2][s - 1] = j0[2]; J[3][s - 1] = j0[3];
             J[4][s - 1] = j1[0]; J[5][s - 1] = j1[1];
@@ -522,6 +590,14 @@ template <int WIDTH> struct MlpEngineTiled8 {
         last_layer(plan.n_layers - 1);
         AC_MARK(st, 5);
         AC_MARK(st, 6);
+    }
+    // the MlpCoeffs interface of the value-only engines: y now (J unused)
+    template <int JC> AC_DI void forward(const float z[5], float y[6], float (*J)[JC]) {
+        static_assert(SL == 1, "the tangent engine keeps its outputs in LDS: MlpLazyCoeffs");
+        forward_keep(z);
+        const f32x4 y0 = *reinterpret_cast<const f32x4*>(act + row_of(0) * S), y1 = *reinterpret_cast<const f32x4*>(act + row_of(0) * S + 4);
+        y[0] = y0[0]; y[1] = y0[1]; y[2] = y0[2]; y[3] = y0[3]; y[4] = y1[0]; y[5] = y1[1];
+        (void)J;
     }
 };
 
@@ -801,6 +877,46 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_rollout_tiled(const DevParams 
         if (k + 1 < H) load_rows<7>(U + (k + 1) * 7 * B, B, i, un);
         state_update_carry(P, coeffs, xa, u, dt);
         if (live) {
+            float* o = Xout + (k + 1) * 13 * B;
+#pragma unroll
+            for (int r = 0; r < 13; ++r) o[(long)r * B + i] = (float)xa[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 7; ++r) u[r] = un[r];
+    }
+}
+
+// Sequential rollout of SMALL batches (cfg2's own B = 256): 8 instances per wave on the value-only 8-unit tile, the eight
+// lanes of an instance compute the same rigid-body values (its share of the work is small; what counts here is the latency
+// of the 4 H sequential network evaluations), lane tj = 0 writes.  State carried in float64 like every rollout kernel.
+template <int WIDTH> constexpr int kRolloutUnits = WIDTH == 64 ? 4 : 8;  // instances per wave of k_nn_rollout_tiled8
+template <int WIDTH>
+__global__ __launch_bounds__(kBlock) void k_nn_rollout_tiled8(const DevParams P, const ValuPlan plan,
+                                                              const float* __restrict__ blob,
+                                                              const float* __restrict__ X0, const float* __restrict__ U,
+                                                              float dt, long B, long H, float* __restrict__ Xout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef MlpEngineTiled8<WIDTH, 1, kRolloutUnits<WIDTH>> Engine;
+    Engine eng(plan, blob, smem);
+    eng.load_weights();
+    const long raw = ((long)blockIdx.x * (kBlock >> 6) + (threadIdx.x >> 6)) * Engine::kUnits + eng.unit;
+    const bool live = raw < B, writer = live && eng.tj == 0;
+    const long i = live ? raw : B - 1;
+    float x[13], u[7], un[7];
+    load_rows<13>(X0, B, i, x);
+    double xa[13];
+#pragma unroll
+    for (int r = 0; r < 13; ++r) xa[r] = (double)x[r];
+    if (writer) {
+#pragma unroll
+        for (int r = 0; r < 13; ++r) Xout[(long)r * B + i] = x[r];
+    }
+    if (H > 0) load_rows<7>(U, B, i, u);
+    MlpCoeffs<Engine> coeffs(eng);
+    for (long k = 0; k < H; ++k) {
+        if (k + 1 < H) load_rows<7>(U + (k + 1) * 7 * B, B, i, un);
+        state_update_carry(P, coeffs, xa, u, dt);
+        if (writer) {
             float* o = Xout + (k + 1) * 13 * B;
 #pragma unroll
             for (int r = 0; r < 13; ++r) o[(long)r * B + i] = (float)xa[r];

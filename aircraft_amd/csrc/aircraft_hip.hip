@@ -672,6 +672,28 @@ int ac_rollout_f32(ac_handle* h, const float* X0, const float* U, float dt, long
     if (rc != AC_OK) return rc;
     if (B == 0) return AC_OK;
     hipStream_t st = (hipStream_t)stream;
+    const long roll_units = h->vwidth == 64 ? kRolloutUnits<64> : kRolloutUnits<32>;  // instances per wave of k_nn_rollout_tiled8
+    if (h->dp.p.model_kind == AC_MODEL_NN && !h->use_mfma && h->has_vplan && B <= roll_units * 4 * (long)(h->num_cus > 0 ? h->num_cus : 256)) {
+        // small batches (at most one wave per SIMD): the latency of the 4 H sequential network evaluations is what counts —
+        // the value-only tile with 4 or 8 instances per wave, four waves per workgroup
+        const int grid = (int)((B + 4 * roll_units - 1) / (4 * roll_units));
+        const int lds = h->vplan.image_floats * 4 + 4 * (int)roll_units * (h->vwidth + 4) * 4;
+        bool launched = false;
+#define AC_TILED_ROLL8(W_)                                                                                         \
+        if (h->vwidth == W_) {                                                                                     \
+            auto kern = k_nn_rollout_tiled8<W_>;                                                                   \
+            int rc_ = set_lds_limit(h, kern, lds);                                                                 \
+            if (rc_ != AC_OK) return rc_;                                                                          \
+            hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->vplan, h->d_vblob, X0, U, dt, B, H, Xout);   \
+            launched = true;                                                                                       \
+        }
+        AC_TILED_ROLL8(32) AC_TILED_ROLL8(64)
+#undef AC_TILED_ROLL8
+        if (!launched) return fail(AC_ERR_UNSUPPORTED, "no tiled vector-ALU kernel instance for this hidden width");
+        note_launch(h, "k_nn_rollout_tiled8", grid, kBlock, lds);
+        AC_HIP(hipGetLastError());
+        return AC_OK;
+    }
     if (h->dp.p.model_kind == AC_MODEL_NN && !h->use_mfma && h->has_vplan) {
         const int grid = (int)((B + kBlock - 1) / kBlock);
         const int lds = h->vplan.image_floats * 4 + 4 * 64 * (h->vwidth + 4) * 4;
@@ -798,7 +820,12 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
             if (h->all_pair) { n_main = 0; n_pair = n; }
         }
         if (n_main > 0) {
-            const int grid = (int)((n_main + 63) / 64);
+            // persistent: at most one workgroup per CU, each walks the 64-unit tasks b, b + grid, ... (k_nn_step_sens)
+#ifndef AC_NO_PERSIST
+            const int grid = (int)std::min<long>((n_main + 63) / 64, cus);
+#else
+            const int grid = (int)((n_main + 63) / 64);  // (A/B flavour: a workgroup per task, as in round 2)
+#endif
             bool launched = false;
             AC_NN_CASE_SENS(2, true, (k_nn_step_sens<2, true>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)
             AC_NN_CASE_SENS(4, true, (k_nn_step_sens<4, true>), grid, kBlock, X, U, dt, dt_per_unit, n_main, blk, Xn, A, Bm, c)

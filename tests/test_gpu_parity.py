@@ -179,7 +179,8 @@ def test_rollout_in_envelope(gpu):
 # (model, B, H).  The reference's networks/linearised.csv has a positive C_Z-alpha slope (anti-lift): that model
 # diverges to inf within ~20 steps, so it is rolled out over a short horizon only.
 ROLLOUT_CASES = [("default", 257, 50), ("linear", 100, 8), ("poly", 257, 50), ("real", 600, 50),
-                 ("cfg2_3x64", 256, 50), ("cfg2_3x64_valu", 70, 20), ("cfg3_4x128", 64, 50), ("cfg3_4x128", 320, 100)]
+                 ("cfg2_3x64", 256, 50), ("cfg2_3x64_valu", 70, 20), ("cfg2_3x64_valu", 256, 50), ("cfg2_3x64_valu", 9000, 12),
+                 ("cfg3_4x128", 64, 50), ("cfg3_4x128", 320, 100)]
 
 
 # lower bounds on the fraction of instances (with a finite float64 reference) that meet the plain 1e-5 bar at EVERY node
@@ -198,6 +199,8 @@ def test_rollout(gpu, model, B, H):
     ac = build(model, normalise=True)
     X0, U = synthetic_problem(B, H, seed=17)
     out = ac.rollout(dev(X0, gpu), dev(U, gpu), 0.01).cpu().numpy()
+    if model == "cfg2_3x64_valu":  # "MFMA off": small batches on the few-instances-per-wave tile, large ones 64 per wave
+        assert ac.last_launch()[0] == ("k_nn_rollout_tiled8" if B <= 4096 else "k_nn_rollout_tiled")
     ref, cond = conditioning(make_oracle(ac), X0, U, 0.01)
     assert np.array_equal(out[0], X0.astype(np.float32))
     check_against_conditioning(f"rollout[{model}-{B}-{H}]", out, ref, cond, STATE_TOL, min_frac=ROLLOUT_MIN_FRAC[model])
