@@ -4,7 +4,8 @@ sampled Dubins path — the `eval` / `eval_tangent` / `length` trio `MHTT` asks 
 
 Host side is float64 numpy and keeps the reference's closed-interval segment test (a value exactly on an interior
 knot is counted by both neighbours, initialisation.py:818-819) so `length()` returns the reference's number.
-`install()` hands the segment cubics to the HIP handle for the device kernels (csrc/ac_track.hpp).
+`install()` hands the segment cubics to the HIP handle for the device kernels (csrc/ac_track.hpp), which reproduce the
+double count at the knots an fp32 progress value can hit exactly.
 The Dubins path construction itself (initialisation.py:94-226, 594) is out of scope: pass its sampled points.
 """
 from __future__ import annotations

@@ -4,9 +4,11 @@
 //
 // The host computes the Hermite slopes in float64 and hands over one cubic per segment and axis,
 //   pos_a(t) = c[a][0] + c[a][1] t + c[a][2] t^2 + c[a][3] t^3,   t = s (n-1) - seg,   d pos/ds = pos'(t) (n-1),
-// so a lookup is one index computation and 12 loads.  Segments here are half-open; the reference's closed
-// intervals count a value twice when s sits exactly on an interior knot (a measure-zero artefact).
-// Outside [0,1] the position is the end knot and the tangent is zero (initialisation.py:821-823).
+// so a lookup is one index computation and 12 loads.  The reference sums its segments over CLOSED intervals
+// (initialisation.py:818-819: s >= s0 and s <= s1), so a progress value exactly on an interior knot is counted by both
+// neighbours — position and tangent come out as the SUM of the two one-sided values (twice the knot).  Reproduced here for
+// the only progress values that can do that in fp32: those equal to a knot whose float64 value is fp32-representable
+// (flags from ac_set_track).  Outside [0,1] the position is the end knot and the tangent is zero (:821-823).
 #pragma once
 #include "ac_math.hpp"
 
@@ -14,6 +16,7 @@ namespace ac {
 
 struct TrackDev {
     const float* __restrict__ coef;  // [nseg][3][4]
+    const float* __restrict__ knot_exact;  // [nseg + 1]: 1 where the knot's float64 value is an fp32 number
     int nseg;
     float inv_length;   // 1 / track.length()
     float end_pos[3];   // track.eval(1.0), the terminal-alignment target (moving_horizon.py:91)
@@ -36,6 +39,16 @@ AC_DI void track_eval(const TrackDev& T, float s, float pos[3], float tan[3]) {
         pos[a] = fmaf(fmaf(fmaf(c3, t, c2), t, c1), t, c0);
         const float d = fmaf(fmaf(3.f * c3, t, 2.f * c2), t, c1) * (float)T.nseg;
         tan[a] = (below || above) ? 0.f : d;
+    }
+    // exactly on an interior knot: the closed interval of the segment to the left holds s too (its t = 1)
+    if (t == 0.f && seg > 0 && !below && T.knot_exact[seg] != 0.f && s == (float)seg / (float)T.nseg) {
+        const float* cl = c - 12;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float c1 = cl[a * 4 + 1], c2 = cl[a * 4 + 2], c3 = cl[a * 4 + 3];
+            pos[a] += ((c3 + c2) + c1) + cl[a * 4];  // the same Horner evaluation at t = 1
+            tan[a] += ((3.f * c3 + 2.f * c2) + c1) * (float)T.nseg;
+        }
     }
 }
 

@@ -1298,14 +1298,25 @@ int ac_set_track(ac_handle* h, int n_segments, const float* coef, float length) 
     AC_ENTER(h);
     if (h->d_track) { (void)hipFree(h->d_track); h->d_track = nullptr; }
     memset(&h->track, 0, sizeof(h->track));  // no dangling device pointer if anything below fails
-    const size_t bytes = (size_t)n_segments * 12 * sizeof(float);
+    // [nseg][3][4] cubics, then one flag per knot: is the knot's float64 value (numpy linspace(0, 1, nseg + 1): i * step, the
+    // last one exactly 1) representable in fp32?  Only such a knot can be hit EXACTLY by an fp32 progress value — where the
+    // reference's closed segment intervals count the point twice (track_eval, ac_track.hpp).
+    std::vector<float> img((size_t)n_segments * 12 + (size_t)n_segments + 1);
+    memcpy(img.data(), coef, (size_t)n_segments * 12 * sizeof(float));
+    const double step = 1.0 / (double)n_segments;
+    for (int i = 0; i <= n_segments; ++i) {
+        const double si = (i == n_segments) ? 1.0 : (double)i * step;
+        img[(size_t)n_segments * 12 + (size_t)i] = ((double)(float)si == si) ? 1.f : 0.f;
+    }
+    const size_t bytes = img.size() * sizeof(float);
     {
         hipError_t e = hipMalloc((void**)&h->d_track, bytes);
         if (e != hipSuccess) { h->d_track = nullptr; return hip_fail(e, "hipMalloc(track)"); }
-        e = hipMemcpy(h->d_track, coef, bytes, hipMemcpyHostToDevice);
+        e = hipMemcpy(h->d_track, img.data(), bytes, hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(h->d_track); h->d_track = nullptr; return hip_fail(e, "hipMemcpy(track)"); }
     }
     h->track.coef = h->d_track;
+    h->track.knot_exact = h->d_track + (size_t)n_segments * 12;
     h->track.nseg = n_segments;
     h->track.inv_length = 1.f / length;
     const float* last = coef + (size_t)(n_segments - 1) * 12;

@@ -7,8 +7,10 @@ Follows the reference line by line, scalar loops and all:
   progress_tight / step_terms                control/moving_horizon.py:147-175
   mhtt_loss                                  control/moving_horizon.py:44-105
 
-PARITY UNPINNED: the reference holds no stored progress data or test for these functions, and it needs casadi (not
-in this image) to run, so this restatement is checked only against hand-computed cases (tests/test_track_oracle.py).
+PARITY UNPINNED for the evaluation: the reference holds no stored progress data or test for these functions, and it needs
+casadi (not in this image) to run, so this restatement is checked against hand-computed cases only
+(tests/test_track_oracle.py).  Its INPUT is pinned: tests/golden/dubins_track.npz is the sampled Dubins path of the
+reference's own problem definition, produced by the reference's aircraft.dubins (tests/golden/make_fixtures.py).
 Only tests/ may import this module.
 """
 import numpy as np

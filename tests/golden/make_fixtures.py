@@ -163,9 +163,58 @@ def scaledmodel_golden():
     print("known answer:", y32[0])
 
 
+def dubins_track():
+    """The sampled 3-D Dubins path of the reference's own problem (data/glider/problem_definition.json: initial state,
+    four waypoints, r_min) — the geometry `DubinsInitialiser` hands to MHTT as its track (control/initialisation.py:573-598).
+    The Dubins construction and its sampling are the REFERENCE's code, imported (aircraft.dubins has no casadi dependency);
+    the waypoint headings / pitches around it restate setup_waypoints_3d (:350-410) and the per-segment sampling rule restates
+    generate_3d_dubins_path_native (:412-470), because that module imports casadi and cannot be imported here.
+    What this pins: the INPUTS of the track functions (the path points).  The CasADi evaluation of the Hermite interpolant
+    over them (:782-851) still cannot run here: oracle/track_oracle.py restates it."""
+    import math
+
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, f"{REF}/src")
+    from aircraft.dubins.dubins3d import DubinsManeuver3D_constructor, compute_sampling  # reference code, imported
+
+    pd = json.load(open(f"{REF}/data/glider/problem_definition.json"))
+    wps = [list(map(float, w)) for w in pd["waypoints"]["waypoints"]]
+    x0 = [float(v) for v in pd["waypoints"]["initial_state"]]
+    r_min = float(pd["aircraft"]["r_min"])
+    lim = [-math.pi / 2, math.pi / 2]  # DubinsInitialiser's default pitch limits (:580)
+
+    def aim(a, b):  # heading and pitch of the straight line a -> b, pitch clipped to the limits
+        dx, dy, dz = b[0] - a[0], b[1] - a[1], b[2] - a[2]
+        return math.atan2(dy, dx), math.atan2(dz, math.hypot(dx, dy))
+
+    # configuration (x, y, z, heading, pitch) per waypoint: the start aims at waypoint 1 from the initial position (the
+    # reference replaces waypoint 0 by the initial position), inner waypoints aim at their successor, the last keeps the
+    # direction of the one before it
+    hd, pt = aim(x0[:3], wps[1])
+    conf = [[x0[0], x0[1], x0[2], hd, pt]]
+    for i in range(1, len(wps)):
+        if i < len(wps) - 1:
+            hd, pt = aim(wps[i], wps[i + 1])
+            pt = min(max(pt, lim[0]), lim[1])
+        else:
+            hd, pt = conf[-1][3], conf[-1][4]
+        conf.append([wps[i][0], wps[i][1], wps[i][2], hd, pt])
+    pts, seg_len = [], []
+    for qi, qf in zip(conf[:-1], conf[1:]):
+        man = DubinsManeuver3D_constructor(qi, qf, r_min, lim)
+        ns = max(50, int(man.length / 2.0))
+        pts += [[float(p[0]), float(p[1]), float(p[2])] for p in compute_sampling(man, ns)]
+        seg_len.append(float(man.length))
+    pts = np.asarray(pts, dtype=np.float64)
+    np.savez(f"{OUT}/dubins_track.npz", points=pts, configurations=np.asarray(conf), segment_lengths=np.asarray(seg_len),
+             r_min=r_min, initial_state=np.asarray(x0), default_velocity=float(pd["waypoints"]["default_velocity"]))
+    print("dubins_track.npz", pts.shape, "segment lengths", seg_len)
+
+
 if __name__ == "__main__":
     decode_simulation_h5()
     decode_poly()
     decode_linear()
     decode_params()
     scaledmodel_golden()
+    dubins_track()

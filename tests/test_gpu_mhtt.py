@@ -58,6 +58,57 @@ def test_track_eval_matches_host_track(gpu):
     assert not f64(tan)[:, -2:].any() and np.allclose(f64(pos)[:, -1], mh.track.points[-1], atol=1e-4)
 
 
+def test_reference_dubins_track_on_the_device(gpu):
+    """The reference's own geometry (tests/golden/dubins_track.npz: the sampled Dubins path of problem_definition.json) on the
+    device: ac_track_eval_f32 against the line-by-line restatement, INCLUDING progress values exactly on a knot, where the
+    reference's closed segment intervals return the sum of both one-sided values (twice the knot), and the progress recursion
+    and loss of gliders flying along it."""
+    import track_oracle as to
+    from tests.helpers import golden
+    from aircraft_amd.control import MHTT, Track
+
+    g = golden("dubins_track.npz")
+    P = g["points"]
+    ac = make_aircraft("poly")
+    track = Track(P)
+    H = 20
+    mh = MHTT(system=ac, track=track, dt=0.01, num_nodes=H, alphas=(1.0, 0.5, 0.1))
+    tro = to.TrackOracle(P)
+    rng = np.random.default_rng(0)
+    knots = np.array([0.5, 0.25, 0.75, 0.125, 0.375, 0.625, 0.875])  # k / 200 representable in fp32: hit exactly
+    near = np.float32(1 / 200) * np.arange(1, 12, dtype=np.float32)   # fp32 products next to knots that are NOT fp32 numbers
+    s = f32_exact(np.concatenate([rng.uniform(0, 1, 400), knots, near, [0.0, 1.0, -0.2, 1.3]]))
+    pos, tan = mh.track_eval(dev(s, gpu))
+    want_p = np.stack([tro.eval(float(v)) for v in s], axis=1)
+    want_t = np.stack([tro.eval_tangent(float(v)) for v in s], axis=1)
+    assert np.abs(f64(pos) - want_p).max() < 5e-4            # metres, on coordinates up to ~400 (twice a knot)
+    assert np.abs(f64(tan) - want_t).max() / np.abs(want_t).max() < 5e-5
+    assert np.allclose(f64(pos)[:, 400], 2 * P[100], atol=5e-4)  # s = 0.5 = knot 100, counted by both segments
+    # gliders released on the first straight of the path, flying along it (the path climbs at 45 degrees there: they do not
+    # follow it for long, which is immaterial to the recursion being checked)
+    B = 32
+    X0 = np.zeros((13, B))
+    s_start = rng.uniform(0.001, 0.01, B)
+    X0[0:3] = np.stack([tro.eval(float(v)) for v in s_start], axis=1) + rng.normal(0, 0.5, (3, B))
+    th = np.stack([tro.eval_tangent(float(v)) for v in s_start], axis=1); th /= np.linalg.norm(th, axis=0)
+    from aircraft_amd.synthetic import quat_from_euler
+    X0[3:6] = 50.0 * th
+    X0[6:10] = quat_from_euler(np.zeros(B), -np.arcsin(th[2]), np.arctan2(th[1], th[0]))  # nose along the velocity
+    U = np.zeros((H, 7, B))
+    X0, s0 = f32_exact(X0), f32_exact(s_start)
+    X = mh.rollout(dev(X0, gpu), dev(U, gpu))
+    Xh, L = f64(X), mh.track_length
+    assert np.isfinite(Xh).all()
+    for mode in (0, 1):
+        S = mh.progress(X, dev(s0, gpu), mode=mode)
+        want = to.progress_initial(tro, L, Xh, s0, mh.dt) if mode == 0 else to.progress_tight(tro, L, Xh, s0, mh.dt)[0]
+        assert np.abs(f64(S) - want).max() < 2e-6
+    S1 = mh.progress(X, dev(s0, gpu), mode=1)
+    J = mh.loss(X, dev(U, gpu), S1)
+    wantJ = to.mhtt_loss(tro, L, Xh, U, f64(S1))
+    assert np.abs(f64(J) - wantJ).max() / np.abs(wantJ).max() < 2e-5
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_progress_recursion_matches_restatement(gpu, mode):
     import track_oracle as to

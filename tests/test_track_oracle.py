@@ -137,3 +137,33 @@ def test_node_cost_restatement_reduces_to_the_constant_cost():
     # a linear term shifts the gradient only
     ng = rng.normal(size=nq.shape)
     assert np.allclose(io.cost(c, X, U, node=(nq, nx, ng)) - io.cost(c, X, U), (ng * X).sum(axis=(0, 1)))
+
+
+def test_reference_dubins_geometry():
+    """The track of the reference's OWN problem: tests/golden/dubins_track.npz is the sampled 3-D Dubins path that
+    DubinsInitialiser builds for data/glider/problem_definition.json (make_fixtures.py::dubins_track runs the reference's
+    aircraft.dubins for it).  This pins the INPUT of the track functions to the reference's geometry; their CasADi evaluation
+    cannot run here, so the restatement stays the checker for eval / eval_tangent / length."""
+    from tests.helpers import golden
+
+    g = golden("dubins_track.npz")
+    P, conf = g["points"], g["configurations"]
+    assert P.shape == (201, 3)
+    # the path starts at the initial position, ends at the last waypoint and passes through the inner ones
+    assert np.allclose(P[0], g["initial_state"][:3]) and np.allclose(P[-1], conf[-1, :3], atol=1e-9)
+    for wp in conf[1:-1, :3]:
+        assert np.linalg.norm(P - wp, axis=1).min() < 1e-9
+    # sampled chord length ~ the manoeuvre lengths the reference's Dubins code reports (50 + 76 + 75 samples; each segment's
+    # sample count max(50, int(length / 2)))
+    chord = np.linalg.norm(np.diff(P, axis=0), axis=1).sum()
+    assert abs(chord - g["segment_lengths"].sum()) / g["segment_lengths"].sum() < 2e-2
+    t, T = to.TrackOracle(P), Track(P)
+    rng = np.random.default_rng(3)
+    exact_knots = [0.5, 0.25, 0.75, 0.125, 0.875]   # k / 200 that are binary fractions: hit exactly, counted twice
+    for s in list(rng.uniform(-0.05, 1.05, 80)) + exact_knots + [0.0, 1.0, 0.005, np.nextafter(0.5, 1)]:
+        assert np.allclose(T.eval(s), t.eval(s), rtol=0, atol=1e-10)
+        assert np.allclose(T.eval_tangent(s), t.eval_tangent(s), rtol=1e-12, atol=1e-7)
+    k = 100  # s = 0.5 is knot 100: the closed segments [99, 100] and [100, 101] both hold it
+    assert np.allclose(T.eval(0.5), 2 * P[k], atol=1e-10) and np.allclose(T.eval(np.nextafter(0.5, 1)), P[k], atol=1e-6)
+    assert np.isclose(T.length(), t.length(), rtol=1e-12)
+    assert 0.9 * g["segment_lengths"].sum() < T.length() < 1.2 * g["segment_lengths"].sum()
