@@ -79,6 +79,9 @@ PROTOTYPES = {
     "ac_shoot_envelope_f32": (C.c_int, [_VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP]),
     "ac_envelope_cost_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
     "ac_envelope_model_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP]),
+    "ac_envelope_al_cost_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, _VP, C.c_long, C.c_long, _VP, _VP]),
+    "ac_envelope_al_model_f32": (C.c_int, [_VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP]),
+    "ac_envelope_al_update_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP]),
     "ac_quat_rows_f32": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP]),
     "ac_step_hess_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _VP, C.c_long, _VP, _VP]),
     "ac_reserve_hess_workspace": (C.c_int, [_VP, C.c_long]),

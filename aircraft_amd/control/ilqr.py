@@ -80,16 +80,20 @@ class QuadraticCost:
 class ILQR(MultipleShooting):
     def __init__(self, *, system, dt: float = 0.01, num_nodes: int, cost: QuadraticCost, opts: Optional[dict] = None,
                  alphas: Sequence[float] = (1.0, 0.5, 0.25, 0.1, 0.03), hessian: str = "gauss-newton",
-                 envelope_weight: float = 0.0, envelope_bounds=None):
+                 envelope_weight: float = 0.0, envelope_bounds=None, envelope: str = "penalty"):
         """hessian: 'gauss-newton' (first-order dynamics in the backward pass: iLQR) or 'exact' (adds the second-order
         terms  sum_i lambda_i d2F_i/dz dz  of every node — what IPOPT gets from `nlp_hess_l`).
         envelope_weight > 0: the flight envelope of AircraftControl.state_constraint (control/aircraft.py:44-59:
         20^2 <= |v_rel|^2 <= 100^2, |beta| <= 10 deg, |alpha| <= 20 deg, z < 0) as a soft constraint — the squared violation
         of its four rows, times the weight, at every node, with its Gauss-Newton model in the backward pass (IPOPT
         enforces the rows as hard constraints; the control box stays a hard clip).  envelope_bounds: ((lo, hi),) * 4,
-        default `system.ENVELOPE_BOUNDS`."""
+        default `system.ENVELOPE_BOUNDS`.
+        envelope: 'penalty' (the soft form above) or 'al' — the HARD treatment: augmented-Lagrangian multipliers per node, row
+        and instance (ac_envelope_al_*), updated by `update_multipliers()` between sweeps (`solve(al_every=)`); the penalty
+        alone leaves a violation of about multiplier / (2 weight) at an active bound, the multipliers remove it."""
         super().__init__(system=system, dt=dt, num_nodes=num_nodes, opts=opts or {"quaternion": "integration"})
-        assert 1 <= len(alphas) <= 8 and hessian in ("gauss-newton", "exact")
+        assert 1 <= len(alphas) <= 8 and hessian in ("gauss-newton", "exact") and envelope in ("penalty", "al")
+        self.envelope_mode = envelope
         self.cost = cost
         self.alphas = [float(a) for a in alphas]
         self.hessian_mode = hessian
@@ -120,6 +124,8 @@ class ILQR(MultipleShooting):
                                 env_xref=nx[:, :, None].expand(H + 1, 13, B).contiguous(), env_glin=f(H + 1, 13, B))
                 if "Hz" not in self._ws:
                     self._ws["Hz"] = f(H, 21, 21, B)
+                if self.envelope_mode == "al":
+                    self._ws.update(lam=torch.zeros((H + 1, 8, B), device=dev, dtype=torch.float32), viol=f(B))
         return self._ws
 
     def _envelope_struct(self):
@@ -132,14 +138,34 @@ class ILQR(MultipleShooting):
         p.weight = self.envelope_weight
         return p
 
+    def _lam(self):
+        """The multipliers of the augmented-Lagrangian envelope (H+1, 8, B), or None for the plain penalty."""
+        return self._ws.get("lam") if (self._ws is not None and self.envelope_mode == "al") else None
+
     def envelope_cost(self, X, cost_inout):
-        """cost_inout[b] += envelope_weight * sum_k sum_r violation_r(x_k)^2 (in place, on the device)."""
+        """cost_inout[b] += the envelope term of every node of X (in place, on the device): the squared violation times the
+        weight, or its augmented-Lagrangian form with the current multipliers."""
         lib = self.system._sync()
         H, B = X.shape[0] - 1, X.shape[2]
         p = self._envelope_struct()
-        _lib.check(lib.ac_envelope_cost_f32(self.system._handle, C.byref(p), X.data_ptr(), B, H, cost_inout.data_ptr(),
-                                            self.system._stream()), "ac_envelope_cost_f32")
+        lam = self._lam()
+        _lib.check(lib.ac_envelope_al_cost_f32(self.system._handle, C.byref(p), lam.data_ptr() if lam is not None else None,
+                                               lam.shape[2] if lam is not None else 1, X.data_ptr(), B, H,
+                                               cost_inout.data_ptr(), self.system._stream()), "ac_envelope_al_cost_f32")
         return cost_inout
+
+    def update_multipliers(self, X):
+        """First-order multiplier update of the augmented-Lagrangian envelope at the iterate X (in place).  Returns each
+        instance's largest bound excess before the update (B,), relative to the row's range."""
+        lib = self.system._sync()
+        assert self.envelope_mode == "al" and self.envelope_weight > 0
+        H, B = X.shape[0] - 1, X.shape[2]
+        ws = self._workspace(B, X.device)
+        p = self._envelope_struct()
+        ws["viol"].zero_()
+        _lib.check(lib.ac_envelope_al_update_f32(self.system._handle, C.byref(p), X.data_ptr(), B, H, ws["lam"].data_ptr(),
+                                                 ws["viol"].data_ptr(), self.system._stream()), "ac_envelope_al_update_f32")
+        return ws["viol"]
 
     def _envelope_model(self, X, glin=None, Hz=None):
         """Adds the penalty's gradient to glin (N+1, 13, B) and / or its Gauss-Newton curvature to the (x, x) block of
@@ -147,10 +173,11 @@ class ILQR(MultipleShooting):
         lib = self.system._sync()
         H, B = X.shape[0] - 1, X.shape[2]
         p = self._envelope_struct()
-        _lib.check(lib.ac_envelope_model_f32(self.system._handle, C.byref(p), X.data_ptr(), B, H,
-                                             glin.data_ptr() if glin is not None else None,
-                                             Hz.data_ptr() if Hz is not None else None, self.system._stream()),
-                   "ac_envelope_model_f32")
+        lam = self._lam()
+        _lib.check(lib.ac_envelope_al_model_f32(self.system._handle, C.byref(p), lam.data_ptr() if lam is not None else None,
+                                                X.data_ptr(), B, H, glin.data_ptr() if glin is not None else None,
+                                                Hz.data_ptr() if Hz is not None else None, self.system._stream()),
+                   "ac_envelope_al_model_f32")
 
     def _cstruct(self):
         return C.byref(self.cost.struct())
@@ -268,10 +295,11 @@ class ILQR(MultipleShooting):
                                           self.system._stream()), "ac_ilqr_accept_f32")
         return Ja, imp
 
-    def solve(self, x0, U0, iters: int = 10, save_to: Optional[str] = None, save_instance: int = 0):
+    def solve(self, x0, U0, iters: int = 10, save_to: Optional[str] = None, save_instance: int = 0, al_every: int = 0):
         """Rollout from x0 with U0, then `iters` iLQR iterations.  Returns (X, U, cost history (iters+1, B)).
         `save_to` writes instance `save_instance` after every iteration in the reference's trajectory format
-        (iteration_0 = the initial rollout), the role of the IPOPT callback in control/base.py:60-86."""
+        (iteration_0 = the initial rollout), the role of the IPOPT callback in control/base.py:60-86.
+        al_every > 0 (envelope = 'al'): a multiplier update after every al_every-th sweep."""
         torch = _torch()
         U = U0.clone()
         X = self.rollout(x0, U)
@@ -284,6 +312,8 @@ class ILQR(MultipleShooting):
         for it in range(iters):
             J, _ = self.iterate(x0, X, U)
             hist.append(J.clone())
+            if al_every and self.envelope_mode == "al" and (it + 1) % al_every == 0 and it + 1 < iters:
+                self.update_multipliers(X)  # (the objective changes with the multipliers: the history is monotone between updates)
             if save_to:
                 self.save_progress(save_to, it + 1, X, U, save_instance)
         return X, U, torch.stack(hist)

@@ -358,9 +358,34 @@ AC_DI float envelope_violation(const EnvelopePenalty& E, int r, float g) {
     return g > E.hi[r] ? g - E.hi[r] : (g < E.lo[r] ? g - E.lo[r] : 0.f);
 }
 
+// Augmented-Lagrangian form (the HARD treatment of the rows IPOPT enforces, control/aircraft.py:44-59): with multipliers
+// lam_hi, lam_lo >= 0 per node, row and instance,
+//   L_A = w [ max(0, g - hi + lam_hi / 2w)^2 - (lam_hi / 2w)^2 + max(0, lo - g + lam_lo / 2w)^2 - (lam_lo / 2w)^2 ]
+// — the same quadratic penalty on bounds SHIFTED inwards by lam / 2w, so cost, gradient and Gauss-Newton curvature are the
+// penalty kernels' with a shifted violation; the first-order multiplier update lam <- max(0, lam + 2w (g - hi)) is
+// lam <- 2w x (that shifted violation).  lam [H+1][8][B]: rows 0-3 upper, 4-7 lower bounds; NULL = plain penalty.
+struct ShiftedViolation { float v, const_term; };
+AC_DI ShiftedViolation envelope_violation_al(const EnvelopePenalty& E, int r, float g, float lam_hi, float lam_lo) {
+    const float i2w = E.weight > 0.f ? 0.5f / E.weight : 0.f;
+    const float sh = lam_hi * i2w, sl = lam_lo * i2w;
+    const float up = g - E.hi[r] + sh, dn = E.lo[r] - g + sl;   // at most one of them is positive for lo < hi and small shifts
+    ShiftedViolation o;
+    o.v = up > 0.f ? up : (dn > 0.f ? -dn : 0.f);
+    o.const_term = sh * sh + sl * sl;
+    return o;
+}
+AC_DI void load_multipliers(const float* __restrict__ lam, long k, long b, long B, float lh[4], float ll[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        lh[r] = lam ? lam[(k * 8 + r) * B + b] : 0.f;
+        ll[r] = lam ? lam[(k * 8 + 4 + r) * B + b] : 0.f;
+    }
+}
+
 // cost[b] += sum_k penalty_k(x_k), k = 0..H: one lane per instance (X [H+1][13][B])
 template <int INST = 0>
 __global__ __launch_bounds__(kBlock) void k_envelope_cost(const DevParams P, const EnvelopePenalty E,
+                                                          const float* __restrict__ lam, long Bl,
                                                           const float* __restrict__ X, long B, long H,
                                                           float* __restrict__ cost) {
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -372,10 +397,46 @@ __global__ __launch_bounds__(kBlock) void k_envelope_cost(const DevParams P, con
         AeroPre<float> a;
         aero_pre(P, x, a);
         const float g[4] = {a.vr[0] * a.vr[0] + a.vr[1] * a.vr[1] + a.vr[2] * a.vr[2], a.beta, a.alpha, x[2]};
+        float lh[4], ll[4];
+        load_multipliers(lam, k, i % Bl, Bl, lh, ll);  // (a batch of line-search candidates reads instance b % Bl)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float v = envelope_violation(E, r, g[r]); acc = fmaf(v, v, acc); }
+        for (int r = 0; r < 4; ++r) {
+            const ShiftedViolation sv = envelope_violation_al(E, r, g[r], lh[r], ll[r]);
+            acc = fmaf(sv.v, sv.v, acc) - sv.const_term;
+        }
     }
     cost[i] += E.weight * acc;
+}
+
+// First-order multiplier update at the iterate X [H+1][13][B]: lam <- 2 w x (shifted violation), one lane per (node,
+// instance); viol_max [B] (may be NULL; zero it first): the largest |g - bound| excess of the instance, unshifted, each row
+// scaled by `scale[r]` so that the four rows compare (atomic max on the bits of a non-negative float).
+template <int INST = 0>
+__global__ __launch_bounds__(kBlock) void k_envelope_multipliers(const DevParams P, const EnvelopePenalty E,
+                                                                 const float* __restrict__ X, long B, long H,
+                                                                 float* __restrict__ lam, float* __restrict__ viol_max) {
+    const long t = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (H + 1) * B) return;
+    const long k = t / B, b = t % B;
+    float x[13];
+    load_rows<13>(X + k * 13 * B, B, b, x);
+    AeroPre<float> a;
+    aero_pre(P, x, a);
+    const float g[4] = {a.vr[0] * a.vr[0] + a.vr[1] * a.vr[1] + a.vr[2] * a.vr[2], a.beta, a.alpha, x[2]};
+    float lh[4], ll[4];
+    load_multipliers(lam, k, b, B, lh, ll);
+    const float w2 = 2.0f * E.weight;
+    float worst = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float up = g[r] - E.hi[r], dn = E.lo[r] - g[r];
+        lam[(k * 8 + r) * B + b] = fmaxf(0.f, fmaf(w2, up, lh[r]));
+        lam[(k * 8 + 4 + r) * B + b] = fmaxf(0.f, fmaf(w2, dn, ll[r]));
+        const float span = E.hi[r] - E.lo[r];
+        const float sc = (span > 0.f && span < 1e30f) ? 1.0f / span : 1.0f;  // relative to the row's range where it has one
+        worst = fmaxf(worst, fmaxf(up, dn) * sc);
+    }
+    if (viol_max && worst > 0.f && worst == worst) atomicMax(reinterpret_cast<int*>(viol_max) + b, __float_as_int(worst));
 }
 
 // Quadratic model of the penalty around the iterate, in the form the backward pass consumes: the gradient
@@ -384,6 +445,7 @@ __global__ __launch_bounds__(kBlock) void k_envelope_cost(const DevParams P, con
 // One lane per (node, instance).
 template <int INST = 0>
 __global__ __launch_bounds__(kBlock) void k_envelope_model(const DevParams P, const EnvelopePenalty E,
+                                                           const float* __restrict__ lam,
                                                            const float* __restrict__ X, long B, long H,
                                                            float* __restrict__ node_glin, float* __restrict__ Hz) {
     const long t = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -398,10 +460,11 @@ __global__ __launch_bounds__(kBlock) void k_envelope_model(const DevParams P, co
     AeroPre<T> a;
     aero_pre(P, x, a);
     const T row[3] = {a.vr[0] * a.vr[0] + a.vr[1] * a.vr[1] + a.vr[2] * a.vr[2], a.beta, a.alpha};
-    float viol[4], grad[4][13];
+    float viol[4], grad[4][13], lh[4], ll[4];
+    load_multipliers(lam, k, b, B, lh, ll);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        viol[r] = envelope_violation(E, r, r < 3 ? row[r].v : xv[2]);
+        viol[r] = envelope_violation_al(E, r, r < 3 ? row[r].v : xv[2], lh[r], ll[r]).v;
 #pragma unroll
         for (int j = 0; j < 13; ++j) grad[r][j] = r < 3 ? ((j >= 3 && j < 10) ? row[r].d[j - 3] : 0.f) : (j == 2 ? 1.f : 0.f);
     }

@@ -969,29 +969,53 @@ static EnvelopePenalty to_dev_penalty(const ac_envelope_penalty* p) {
     return d;
 }
 
-int ac_envelope_cost_f32(ac_handle* h, const ac_envelope_penalty* pen, const float* X, long B, long H, float* cost,
-                         void* stream) {
+int ac_envelope_al_cost_f32(ac_handle* h, const ac_envelope_penalty* pen, const float* lam, long Bl, const float* X, long B,
+                            long H, float* cost, void* stream) {
     AC_ENTER(h);
     if (h && B == 0) return AC_OK;
-    if (!h || !pen || !X || !cost || B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    if (!h || !pen || !X || !cost || B < 0 || H < 0 || (lam && (!(pen->weight > 0.f) || Bl <= 0 || B % Bl != 0))) return AC_ERR_BAD_ARG;
     if (h->dp.p.model_kind == AC_MODEL_QUAD) return fail(AC_ERR_UNSUPPORTED, "envelope rows are the fixed-wing plugin's (control/aircraft.py)");
     const int grid = (int)((B + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_envelope_cost<0>, grid, kBlock, 0, (hipStream_t)stream, h->dp, to_dev_penalty(pen), X, B, H, cost);
+    hipLaunchKernelGGL(k_envelope_cost<0>, grid, kBlock, 0, (hipStream_t)stream, h->dp, to_dev_penalty(pen), lam, lam ? Bl : 1, X, B, H, cost);
     note_launch(h, "k_envelope_cost", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_envelope_cost_f32(ac_handle* h, const ac_envelope_penalty* pen, const float* X, long B, long H, float* cost,
+                         void* stream) {
+    return ac_envelope_al_cost_f32(h, pen, nullptr, 1, X, B, H, cost, stream);
+}
+
+int ac_envelope_al_model_f32(ac_handle* h, const ac_envelope_penalty* pen, const float* lam, const float* X, long B, long H,
+                             float* node_glin, float* Hz, void* stream) {
+    AC_ENTER(h);
+    if (h && B == 0) return AC_OK;
+    if (!h || !pen || !X || (!node_glin && !Hz) || B < 0 || H < 0 || (lam && !(pen->weight > 0.f))) return AC_ERR_BAD_ARG;
+    if (h->dp.p.model_kind == AC_MODEL_QUAD) return fail(AC_ERR_UNSUPPORTED, "envelope rows are the fixed-wing plugin's (control/aircraft.py)");
+    const long n = (H + 1) * B;
+    const int grid = (int)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_envelope_model<0>, grid, kBlock, 0, (hipStream_t)stream, h->dp, to_dev_penalty(pen), lam, X, B, H, node_glin, Hz);
+    note_launch(h, "k_envelope_model", grid, kBlock, 0);
     AC_HIP(hipGetLastError());
     return AC_OK;
 }
 
 int ac_envelope_model_f32(ac_handle* h, const ac_envelope_penalty* pen, const float* X, long B, long H, float* node_glin,
                           float* Hz, void* stream) {
+    return ac_envelope_al_model_f32(h, pen, nullptr, X, B, H, node_glin, Hz, stream);
+}
+
+int ac_envelope_al_update_f32(ac_handle* h, const ac_envelope_penalty* pen, const float* X, long B, long H, float* lam,
+                              float* viol_max, void* stream) {
     AC_ENTER(h);
     if (h && B == 0) return AC_OK;
-    if (!h || !pen || !X || (!node_glin && !Hz) || B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    if (!h || !pen || !X || !lam || B < 0 || H < 0 || !(pen->weight > 0.f)) return AC_ERR_BAD_ARG;
     if (h->dp.p.model_kind == AC_MODEL_QUAD) return fail(AC_ERR_UNSUPPORTED, "envelope rows are the fixed-wing plugin's (control/aircraft.py)");
     const long n = (H + 1) * B;
     const int grid = (int)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_envelope_model<0>, grid, kBlock, 0, (hipStream_t)stream, h->dp, to_dev_penalty(pen), X, B, H, node_glin, Hz);
-    note_launch(h, "k_envelope_model", grid, kBlock, 0);
+    hipLaunchKernelGGL(k_envelope_multipliers<0>, grid, kBlock, 0, (hipStream_t)stream, h->dp, to_dev_penalty(pen), X, B, H, lam, viol_max);
+    note_launch(h, "k_envelope_multipliers", grid, kBlock, 0);
     AC_HIP(hipGetLastError());
     return AC_OK;
 }

@@ -168,6 +168,21 @@ int ac_envelope_cost_f32(ac_handle* h, const ac_envelope_penalty* pen, const flo
                          void* stream);
 int ac_envelope_model_f32(ac_handle* h, const ac_envelope_penalty* pen, const float* X, long B, long H, float* node_glin,
                           float* Hz, void* stream);
+/* The envelope as a HARD constraint of the sweep, augmented-Lagrangian form: multipliers lam [H+1][8][B] (device; rows 0-3
+ * the upper, 4-7 the lower bounds of the four envelope rows; all >= 0; start at zero) per node, row and instance —
+ *   L_A = w sum_r max(0, g_r - hi_r + lam_hi / 2w)^2 - (lam_hi / 2w)^2 + max(0, lo_r - g_r + lam_lo / 2w)^2 - (lam_lo / 2w)^2
+ * i.e. the penalty above on bounds shifted inwards by lam / 2w.  ac_envelope_al_cost_f32 / _model_f32 are the two calls above
+ * with that shift (lam NULL = the plain penalty; a cost batch wider than Bl — the line-search candidates — reads the
+ * multipliers of instance b % Bl); ac_envelope_al_update_f32 is the first-order multiplier update at the iterate X,
+ *   lam_hi <- max(0, lam_hi + 2 w (g - hi)),   lam_lo <- max(0, lam_lo + 2 w (lo - g)),
+ * and (viol_max [B] non-NULL, zeroed by the caller) reports each instance's largest bound excess over all nodes and rows,
+ * relative to the row's range where it has one.  The weight must be > 0. */
+int ac_envelope_al_cost_f32(ac_handle* h, const ac_envelope_penalty* pen, const float* lam, long Bl, const float* X, long B,
+                            long H, float* cost, void* stream);
+int ac_envelope_al_model_f32(ac_handle* h, const ac_envelope_penalty* pen, const float* lam, const float* X, long B, long H,
+                             float* node_glin, float* Hz, void* stream);
+int ac_envelope_al_update_f32(ac_handle* h, const ac_envelope_penalty* pen, const float* X, long B, long H, float* lam,
+                              float* viol_max, void* stream);
 
 /* Quaternion rows of ControlProblem.state_constraint on H nodes of X [>=H][13][B] (control/base.py:285-304):
  *   mode 0 ('constraint'):  row = q . q - 1                                                        (:285-286)

@@ -92,3 +92,32 @@ def forward(orc, c, x0, Xnom, U, K, kff, alphas, dt):
             x = orc.state_update(x, u, dt)
             Xc[k + 1, :, sl] = x
     return Xc, Uc
+
+
+# ---- the flight envelope as an augmented-Lagrangian term (ac_kernels_analytic.hpp: k_envelope_cost / _model / _multipliers) ----
+def envelope_al(orc, X, lo, hi, w, lam=None):
+    """X (Hn, 13, B); bounds lo, hi (4,); multipliers lam (Hn, 8, B) (rows 0-3 upper, 4-7 lower; None = zeros: the plain
+    penalty).  Returns (cost (B,), gradient (Hn, 13, B), Gauss-Newton curvature (Hn, 13, 13, B), shifted violation (Hn, 4, B),
+    rows (Hn, 4, B)) of  L_A = w sum_r max(0, g - hi + lam_hi/2w)^2 - (lam_hi/2w)^2 + max(0, lo - g + lam_lo/2w)^2 - (lam_lo/2w)^2."""
+    Hn, _, B = X.shape
+    lam = np.zeros((Hn, 8, B)) if lam is None else np.asarray(lam, dtype=np.float64)
+    cost = np.zeros(B); grad = np.zeros((Hn, 13, B)); curv = np.zeros((Hn, 13, 13, B))
+    sv = np.zeros((Hn, 4, B)); rows_all = np.zeros((Hn, 4, B))
+    for k in range(Hn):
+        rows, Jx = orc.envelope(X[k])
+        sh, sl = lam[k, :4] / (2 * w), lam[k, 4:] / (2 * w)
+        up = rows - hi[:, None] + sh
+        dn = lo[:, None] - rows + sl
+        v = np.where(up > 0, up, np.where(dn > 0, -dn, 0.0))
+        cost += w * ((v ** 2).sum(axis=0) - (sh ** 2).sum(axis=0) - (sl ** 2).sum(axis=0))
+        grad[k] = 2 * w * np.einsum("rb,rjb->jb", v, Jx)
+        curv[k] = 2 * w * np.einsum("rb,rib,rjb->ijb", (v != 0).astype(float), Jx, Jx)
+        sv[k], rows_all[k] = v, rows
+    return cost, grad, curv, sv, rows_all
+
+
+def envelope_al_update(rows, lo, hi, w, lam):
+    """lam_hi <- max(0, lam_hi + 2w (g - hi)), lam_lo <- max(0, lam_lo + 2w (lo - g)); rows (Hn, 4, B) -> new lam (Hn, 8, B)"""
+    up = rows - hi[None, :, None]
+    dn = lo[None, :, None] - rows
+    return np.concatenate([np.maximum(0.0, lam[:, :4] + 2 * w * up), np.maximum(0.0, lam[:, 4:] + 2 * w * dn)], axis=1)

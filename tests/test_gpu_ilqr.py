@@ -262,6 +262,92 @@ def test_envelope_penalty_kernels_match_numpy(gpu):
     assert not Hh[:, 13:].any() and not Hh[:, :, 13:].any()
 
 
+def test_envelope_al_kernels_match_numpy(gpu):
+    """The augmented-Lagrangian form of the envelope rows (ac_envelope_al_cost_f32 / _model_f32 / _update_f32: multipliers per
+    node, row and instance) against the NumPy restatement (oracle/ilqr_oracle.py::envelope_al) on the oracle's rows and exact
+    Jacobians: cost with random multipliers (also for a batch of line-search candidates that shares them), gradient,
+    Gauss-Newton curvature, and the first-order multiplier update."""
+    import torch
+    import ilqr_oracle as io
+    from aircraft_amd.control import ILQR
+    from tests.helpers import synthetic_problem
+
+    B, H, w = 40, 12, 3.0
+    ac, il0, cost, X0, U = setup(gpu, "poly", None, B=B, H=H)
+    il = ILQR(system=ac, dt=0.01, num_nodes=H, cost=cost, alphas=(1.0, 0.5), envelope_weight=w, envelope="al",
+              envelope_bounds=((45.0 ** 2, 60.0 ** 2), (-0.01, 0.01), (-0.02, 0.03), (-1e30, -199.5)))
+    Xs, Us = synthetic_problem(B, H, seed=3)
+    X = il.rollout(dev(X0, gpu), dev(0.3 * Us, gpu))
+    Xh = X.cpu().numpy().astype(np.float64)
+    lo = np.array([b[0] for b in il.envelope_bounds]); hi = np.array([b[1] for b in il.envelope_bounds])
+    ws = il._workspace(B, X.device)
+    rng = np.random.default_rng(8)
+    lam0 = f32_exact(rng.uniform(0, 1, (H + 1, 8, B)) * (rng.uniform(0, 1, (H + 1, 8, B)) < 0.5)
+                     * np.array([50.0, 0.05, 0.05, 2.0] * 2)[None, :, None])
+    lam0[:, 7] = 0.0  # (z has no lower bound: -1e30)
+    ws["lam"].copy_(dev(lam0, gpu))
+    orc = make_oracle(ac)
+    cw, gw, pw, sv, rows = io.envelope_al(orc, Xh, lo, hi, w, lam0)
+    assert (sv != 0).mean() > 0.15  # not vacuous: many shifted violations are active
+    J = torch.full((B,), 7.0, device=gpu)
+    il.envelope_cost(X, J)
+    assert np.abs(J.cpu().numpy() - 7.0 - cw).max() <= 2e-5 * max(np.abs(cw).max(), 1.0)
+    # two line-search candidates per instance, column a * B + b, sharing instance b's multipliers
+    X2 = torch.cat([X, X], dim=2).contiguous()
+    J2 = torch.zeros((2 * B,), device=gpu)
+    il.envelope_cost(X2, J2)
+    assert np.abs(J2.cpu().numpy() - np.tile(cw, 2)).max() <= 2e-5 * max(np.abs(cw).max(), 1.0)
+    glin = torch.zeros((H + 1, 13, B), device=gpu); Hz = torch.zeros((H, 21, 21, B), device=gpu)
+    il._envelope_model(X, glin=glin, Hz=Hz)
+    assert np.abs(glin.cpu().numpy() - gw).max() <= 5e-5 * max(np.abs(gw).max(), 1.0)
+    assert np.abs(Hz.cpu().numpy()[:, :13, :13] - pw[:H]).max() <= 1e-4 * max(np.abs(pw).max(), 1.0)
+    viol = il.update_multipliers(X).cpu().numpy()
+    want = io.envelope_al_update(rows, lo, hi, w, lam0)
+    got = ws["lam"].cpu().numpy()
+    assert (got >= 0).all() and np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1.0)
+    span = np.where((hi - lo) < 1e30, hi - lo, 1.0)
+    exc = (np.maximum(rows - hi[None, :, None], lo[None, :, None] - rows) / span[None, :, None]).max(axis=(0, 1))
+    assert np.abs(viol - np.maximum(exc, 0)).max() <= 2e-5 * max(exc.max(), 1.0)
+    # zero multipliers: the plain penalty, bit for bit
+    ws["lam"].zero_()
+    Ja, Jp = torch.zeros((B,), device=gpu), torch.zeros((B,), device=gpu)
+    il.envelope_cost(X, Ja)
+    ILQR(system=ac, dt=0.01, num_nodes=H, cost=cost, alphas=(1.0, 0.5), envelope_weight=w,
+         envelope_bounds=il.envelope_bounds).envelope_cost(X, Jp)
+    assert torch.equal(Ja, Jp)
+
+
+def test_envelope_multipliers_enforce_what_the_penalty_leaves_violated(gpu):
+    """The hard treatment of the envelope rows (the reference enforces them as NLP constraints, control/aircraft.py:44-59):
+    gliders asked to descend to a goal height below a floor they must not cross (the height row: z <= -198.5 m; the goal
+    is at -185 m).  A quadratic penalty of moderate weight converges to a trajectory that crosses the floor by about
+    multiplier / (2 weight) = 0.38 m; augmented-Lagrangian multipliers of the SAME weight, updated every third sweep, bring
+    the crossing down to centimetres (measured: median 0.02 m, worst instance 0.09 m after eleven updates, still falling)."""
+    from aircraft_amd.control import ILQR, QuadraticCost
+    from tests.helpers import parity_report
+
+    ac, il0, cost, X0, U = setup(gpu, "poly", None, B=48, H=40)
+    cost = QuadraticCost.goal((24.0, 0.0), w_goal=1.0, height=-185.0, w_height=40.0, w_lateral_speed=0.1, r=0.02, reg=1.0)
+    floor = -198.5
+    big = np.deg2rad(20)
+    bounds = ((20.0 ** 2, 100.0 ** 2), (-np.deg2rad(10), np.deg2rad(10)), (-big, big), (-1e30, floor))
+    res = {}
+    for mode in ("penalty", "al"):
+        il = ILQR(system=ac, dt=0.01, num_nodes=40, cost=cost, alphas=(1.0, 0.5, 0.25, 0.1, 0.03), envelope_weight=500.0,
+                  envelope_bounds=bounds, envelope=mode)
+        X, Uo, hist = il.solve(dev(X0, gpu), dev(np.zeros_like(U), gpu), iters=36, al_every=3)
+        rows, _ = il.envelope(X)
+        res[mode] = (rows[:, 3].amax(dim=0) - floor).cpu().numpy()   # how far below the floor (z is down), metres
+        assert np.isfinite(hist.cpu().numpy()).all()
+        if mode == "al":
+            lam = il._ws["lam"].cpu().numpy()
+            assert (lam >= 0).all() and (lam[:, 3] > 0).any() and not lam[:, 7].any()  # the floor's multipliers are the active ones
+    parity_report("envelope_al_vs_penalty", penalty_excess_median_m=float(np.median(res["penalty"])),
+                  al_excess_median_m=float(np.median(res["al"])), al_excess_max_m=float(res["al"].max()))
+    assert np.median(res["penalty"]) > 0.3                       # the penalty alone settles 0.38 m below the floor
+    assert np.median(res["al"]) < 0.06 and res["al"].max() < 0.2   # the multipliers enforce it
+
+
 def test_envelope_penalty_steers_the_solve(gpu):
     """With the envelope as a soft constraint the solve trades goal cost for staying inside: gliders asked to reach a goal
     far below their glide path exceed the alpha bound without the penalty and stay (nearly) inside with it."""
