@@ -40,7 +40,8 @@ class AcParams(C.Structure):
 class IlqrCost(C.Structure):
     """struct ac_ilqr_cost (include/aircraft_hip.h)."""
     _fields_ = [("q", C.c_float * 13), ("qf", C.c_float * 13), ("r", C.c_float * 7), ("x_ref", C.c_float * 13),
-                ("x_goal", C.c_float * 13), ("u_min", C.c_float * 7), ("u_max", C.c_float * 7), ("reg", C.c_float)]
+                ("x_goal", C.c_float * 13), ("u_min", C.c_float * 7), ("u_max", C.c_float * 7), ("reg", C.c_float),
+                ("u_lin", C.c_float * 7), ("dt_row", C.c_int)]
 
 
 class EnvelopePenalty(C.Structure):

@@ -38,6 +38,8 @@ class QuadraticCost:
     u_min: Sequence[float] = field(default_factory=lambda: [-5, -5, -5, 0, 0, 0, 0])
     u_max: Sequence[float] = field(default_factory=lambda: [5, 5, 5, 0, 0, 0, 1])
     reg: float = 1e-3
+    u_lin: Sequence[float] = field(default_factory=lambda: [0.0] * 7)   # linear control cost (the time term)
+    dt_row: int = 0                                                      # > 0: control row carrying dt_k (ILQR(time="variable"))
 
     @staticmethod
     def goal(goal_xy, w_goal=1000.0, w_height=1.0, height=None, w_lateral_speed=1000.0, r=1e-2, reg=1e-3):
@@ -69,18 +71,20 @@ class QuadraticCost:
 
     def struct(self) -> "_lib.IlqrCost":
         s = _lib.IlqrCost()
-        for name, n in (("q", 13), ("qf", 13), ("r", 7), ("x_ref", 13), ("x_goal", 13), ("u_min", 7), ("u_max", 7)):
+        for name, n in (("q", 13), ("qf", 13), ("r", 7), ("x_ref", 13), ("x_goal", 13), ("u_min", 7), ("u_max", 7), ("u_lin", 7)):
             v = [float(x) for x in getattr(self, name)]
             assert len(v) == n, name
             getattr(s, name)[:] = v
         s.reg = float(self.reg)
+        s.dt_row = int(self.dt_row)
         return s
 
 
 class ILQR(MultipleShooting):
     def __init__(self, *, system, dt: float = 0.01, num_nodes: int, cost: QuadraticCost, opts: Optional[dict] = None,
                  alphas: Sequence[float] = (1.0, 0.5, 0.25, 0.1, 0.03), hessian: str = "gauss-newton",
-                 envelope_weight: float = 0.0, envelope_bounds=None, envelope: str = "penalty"):
+                 envelope_weight: float = 0.0, envelope_bounds=None, envelope: str = "penalty",
+                 time: str = "fixed", dt_bounds=(0.005, 0.02), w_time: float = 0.0, r_time: float = 0.0):
         """hessian: 'gauss-newton' (first-order dynamics in the backward pass: iLQR) or 'exact' (adds the second-order
         terms  sum_i lambda_i d2F_i/dz dz  of every node — what IPOPT gets from `nlp_hess_l`).
         envelope_weight > 0: the flight envelope of AircraftControl.state_constraint (control/aircraft.py:44-59:
@@ -94,6 +98,23 @@ class ILQR(MultipleShooting):
         super().__init__(system=system, dt=dt, num_nodes=num_nodes, opts=opts or {"quaternion": "integration"})
         assert 1 <= len(alphas) <= 8 and hessian in ("gauss-newton", "exact") and envelope in ("penalty", "al")
         self.envelope_mode = envelope
+        # time as a decision variable per node (the reference's opts['time'] in ('progress', 'variable'),
+        # control/base.py:276, 339-385; its loss adds the total time, main/control/control.py:44, 66-67): a control row the
+        # force model ignores carries dt_k, boxed by dt_bounds, costed by w_time * dt_k (+ 1/2 r_time dt_k^2); the column of B
+        # for it is c = dF/d(dt) from the sensitivity kernels.
+        assert time in ("fixed", "variable")
+        self.time_row = 0
+        if time == "variable":
+            assert hessian == "gauss-newton", "the exact-Hessian sweep keeps the fixed step"
+            import copy
+
+            self.time_row = 4 if getattr(system, "num_controls", 7) == 4 else 3
+            cost = copy.deepcopy(cost)
+            r = self.time_row
+            cost.u_min, cost.u_max, cost.u_lin, cost.r = list(cost.u_min), list(cost.u_max), list(cost.u_lin), list(cost.r)
+            cost.u_min[r], cost.u_max[r] = float(dt_bounds[0]), float(dt_bounds[1])
+            cost.u_lin[r], cost.r[r], cost.dt_row = float(w_time), float(r_time), r
+            self.cost = cost
         self.cost = cost
         self.alphas = [float(a) for a in alphas]
         self.hessian_mode = hessian
@@ -111,6 +132,8 @@ class ILQR(MultipleShooting):
             self._ws = dict(key=key, F=f(H, 13, B), A=f(H, 13, 13, B), Bm=f(H, 13, 7, B), K=f(H, 7, 13, B), kff=f(H, 7, B),
                             dV=f(2, B), Xc=f(H + 1, 13, na * B), Uc=f(H, 7, na * B), Jc=f(na * B), J0=f(B), Ja=f(B),
                             improved=torch.empty((B,), device=dev, dtype=torch.bool))
+            if self.time_row > 0:
+                self._ws.update(dt=f(H, B), c=f(H, 13, B))
             if self.hessian_mode == "exact":
                 self._ws.update(Lam=f(H, 13, B), Hz=f(H, 21, 21, B))
                 self.system._sync()
@@ -256,7 +279,13 @@ class ILQR(MultipleShooting):
         B = U.shape[2]
         ws = self._workspace(B, U.device)
         na = len(self.alphas)
-        self.linearise(X, U, want_c=False, out=(ws["F"], ws["A"], ws["Bm"], None))
+        if self.time_row > 0:
+            # linearise at the nodes' own steps dt_k = U[k, time_row]; its derivative c = dF/d(dt) IS the column of B for that row
+            ws["dt"].copy_(U[:, self.time_row, :])
+            self.linearise(X, U, dt=ws["dt"], want_c=True, out=(ws["F"], ws["A"], ws["Bm"], ws["c"]))
+            ws["Bm"][:, :, self.time_row, :].copy_(ws["c"])
+        else:
+            self.linearise(X, U, want_c=False, out=(ws["F"], ws["A"], ws["Bm"], None))
         node = self._node_cost(X, U)  # None, or a subclass's per-node arrays (rewritten by it every iteration)
         Hz = None
         env = self.envelope_weight > 0
@@ -302,6 +331,8 @@ class ILQR(MultipleShooting):
         al_every > 0 (envelope = 'al'): a multiplier update after every al_every-th sweep."""
         torch = _torch()
         U = U0.clone()
+        if self.time_row > 0:
+            U[:, self.time_row, :] = self.dt  # every node starts at the nominal step (the rollout below uses it)
         X = self.rollout(x0, U)
         J = self.trajectory_cost(X, U).clone()
         if self.envelope_weight > 0:  # the same objective as every later entry (iterate() adds the penalty)

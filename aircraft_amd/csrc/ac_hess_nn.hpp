@@ -17,6 +17,9 @@
 //                        coefficient provider that applies the chain rule through the stored (y, J, T).
 #pragma once
 #include "ac_kernels_nn.hpp"
+#ifdef AC_EXP_ZERO_REGS
+#include "ac_exp_zero_regs.inc"
+#endif
 
 namespace ac {
 
@@ -42,6 +45,11 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors(const DevParams 
                                                                 float dt, const float* __restrict__ dt_per_unit, long n,
                                                                 long blk, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef AC_EXP_ZERO_REGS  // (experiment flavour only: tools/bisect_exp_last2.sh)
+    AC_ZERO_ALL_REGS();
+    for (int i = threadIdx.x; i < plan.lds_total / 4; i += blockDim.x) reinterpret_cast<volatile float*>(smem)[i] = 0.f;  // and the LDS
+    __syncthreads();
+#endif
     // width <= 64: all five inputs in one pass (21 slabs of 4 WT registers); width 128: four passes over input triples
     constexpr bool kSingle = WT <= 4;
     // width 128: two triples here + the bipartite pass in a second launch (PART 1).  (Not instantiated for the VALU

@@ -21,6 +21,8 @@ struct IlqrCost {
     float x_ref[13], x_goal[13];
     float u_min[7], u_max[7];
     float reg;  // Levenberg term added to the diagonal of Quu
+    float u_lin[7];  // linear control cost  u_lin . u_k  per node (the time term: w_time * dt_k on the time row)
+    int dt_row;      // <= 0: fixed step (a zeroed struct means that); r > 0: control row r carries dt_k as a decision variable (Policy::step)
 };
 
 // Optional per-node, per-instance state cost  l_k(x) = 1/2 sum_j q_k[j] (x_j - xref_k[j])^2 + glin_k . x  (k = 0..H,
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const No
             if constexpr (NODE) { qjj = nd[280 + j]; xr = nd[293 + j]; gl = nd[306 + j]; }
             if (rb == 0) sqx[j] = fmaf(qjj, nd[260 + j] - xr, gl);
         }
-        if (j < 7 && rb == 0) squ[j] = C.r[j] * nd[273 + j];
+        if (j < 7 && rb == 0) squ[j] = fmaf(C.r[j], nd[273 + j], C.u_lin[j]);
         ilqr_sync();
         // This lane's columns of A_k and B_k stay in registers for the node (read once from the ring slot).
         float acol[13], bcol[13];
@@ -420,7 +422,11 @@ __global__ __launch_bounds__(kBlock) void k_ilqr_cost(const IlqrCost C, const No
         }
         if (k < H) {
 #pragma unroll
-            for (int i = 0; i < 7; ++i) { const float u = U[(k * 7 + i) * B + b]; acc = fmaf(0.5f * C.r[i] * u, u, acc); }
+            for (int i = 0; i < 7; ++i) {
+                const float u = U[(k * 7 + i) * B + b];
+                acc = fmaf(0.5f * C.r[i] * u, u, acc);
+                acc = fmaf(C.u_lin[i], u, acc);
+            }
         }
     }
     cost[b] = acc;
@@ -436,6 +442,17 @@ struct Policy {
     long B;                          // nominal batch
     AlphaSet alphas;
     float u_min[7], u_max[7];
+    // Time as a decision variable (the reference's `dt_k` per node, control/base.py:276, 339-385: dt_k = 1 / progress_k^2
+    // in 'progress' time, progress_k^2 in 'variable' time, bounded by dt_bounds): control row `dt_row` — a row the force model
+    // ignores (a thrust row of the fixed-wing plugin) — carries dt_k itself, clipped to its box like every control; the
+    // column of B for it is c = dF/d(dt) of the sensitivity kernels.  dt_row <= 0: the fixed step.
+    int dt_row;
+    AC_DI float step(const float u[7], float dt) const {
+        float r = dt;
+#pragma unroll
+        for (int i = 1; i < 7; ++i) r = (i == dt_row) ? u[i] : r;
+        return r;
+    }
 
     AC_DI void control(long k, long o, const float x[13], float u[7]) const {
         const long b = o % B;
@@ -515,7 +532,7 @@ __global__ __launch_bounds__(64) void k_rollout_policy(const DevParams P, const 
         pol.control(k, o, x, u);
 #pragma unroll
         for (int r = 0; r < 7; ++r) Uout[(k * 7 + r) * Bout + o] = u[r];
-        state_update_carry(P, coeffs, xa, u, dt);
+        state_update_carry(P, coeffs, xa, u, pol.step(u, dt));
         float* out = Xout + (k + 1) * 13 * Bout;
 #pragma unroll
         for (int r = 0; r < 13; ++r) out[(long)r * Bout + o] = (float)xa[r];

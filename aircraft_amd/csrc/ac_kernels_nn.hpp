@@ -398,7 +398,7 @@ AC_DI void rollout_policy_body(const DevParams& P, const MlpPlan& plan, const fl
 #pragma unroll
             for (int r = 0; r < 7; ++r) Uout[(k * 7 + r) * Bout + o] = u[r];
         }
-        state_update_carry(P, coeffs, xa, u, dt);
+        state_update_carry(P, coeffs, xa, u, pol.step(u, dt));
         if (writer) {
             float* out = Xout + (k + 1) * 13 * Bout;
 #pragma unroll

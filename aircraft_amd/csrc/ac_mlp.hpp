@@ -878,16 +878,20 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
         const int L = plan.n_layers;
         AC_MARK(st, 1);  // [1] primal aero + input slab
         if (L == 1) {
-            // Second-order engines decide the activation of the last (here: only) layer ONCE — a wave-uniform branch around
-            // two straight-line bodies — instead of by a runtime flag inside each slab epilogue: hipcc -O2/-O3 miscompiles
-            // the runtime-flag form of the 21-slab instantiation under some register allocations (the round-1
-            // "unexplained sensitivity": reproduced with tools/exp_last2_lib.sh, correct at -O1 and with this form).
-            if constexpr (SECOND) {
-                const char* wl1 = acquire(0);
-                if (plan.act[0]) layer<1, 1, 1>(wl1, 1); else layer<1, 1, 0>(wl1, 0);
-            } else {
-                layer<1, 1>(acquire(0), plan.act[0]);
-            }
+            // Every engine decides the activation of the last (here: only) layer ONCE — a wave-uniform branch around two
+            // straight-line bodies — instead of by a runtime flag inside each slab epilogue.  The runtime form's
+            // `act ? tanh(o) : o` selects come out as v_cndmask pairs that the SLP vectoriser packs into 64-bit registers, and
+            // SIFoldOperands of the ROCm 7.2.0 backend folds the 32-bit copies of their halves into accumulation registers
+            // into a malformed `agpr_32 = REG_SEQUENCE` that loses the subregister index (both halves get the same value):
+            // NaN / 1e19 from k_nn_stage_tensors<2,true,0> on single-layer nets.  Found by opt-bisect + MIR diff —
+            // profiles/r03_exp_last2_miscompile.txt, tools/bisect_exp_last2.sh; tools/check_sifold_regsequence.sh checks every
+            // translation unit of the product for the malformed form.
+#ifdef AC_EXP_RUNTIME_ACT  // (experiment flavour: the form that exposes the defect, tools/bisect_exp_last2.sh)
+            layer<1, 1>(acquire(0), plan.act[0]);
+#else
+            const char* wl1 = acquire(0);
+            if (plan.act[0]) layer<1, 1, 1>(wl1, 1); else layer<1, 1, 0>(wl1, 0);
+#endif
         } else {
             if constexpr (kVLast && kDeriv) first_valu(acquire(0), z);
             else if constexpr (kVLast) first_valu_values(acquire(0), z);
@@ -910,11 +914,9 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
                 AC_MARK(st, 5);  // [5] last layer
                 AC_MARK(st, 6);
                 return;
-            } else if constexpr (SECOND) {  // as for L == 1: no runtime activation flag inside the second-order epilogues
+            } else {  // as for L == 1: no runtime activation flag inside the epilogues
                 const char* wll = acquire(L - 1);
                 if (plan.act[L - 1]) layer<WT, 1, 1>(wll, 1); else layer<WT, 1, 0>(wll, 0);
-            } else {
-                layer<WT, 1>(acquire(L - 1), plan.act[L - 1]);
             }
             AC_MARK(st, 5);  // [5] last layer
         }

@@ -1414,6 +1414,14 @@ int ac_rollout_policy_f32(ac_handle* h, const ac_ilqr_cost* limits, const float*
     for (int i = 0; i < 8; ++i) pol.alphas.a[i] = i < n_alpha ? alphas[i] : 0.f;
     memcpy(pol.u_min, limits->u_min, sizeof(pol.u_min));
     memcpy(pol.u_max, limits->u_max, sizeof(pol.u_max));
+    pol.dt_row = limits->dt_row;
+    if (pol.dt_row >= 7) return AC_ERR_BAD_ARG;
+    if (pol.dt_row > 0) {
+        // the time row must be one the force model ignores, and its box must keep dt positive
+        const bool quad = h->dp.p.model_kind == AC_MODEL_QUAD;
+        if (quad ? pol.dt_row < 4 : (pol.dt_row < 3 || pol.dt_row > 5)) return fail(AC_ERR_BAD_ARG, "dt_row must be a control row without effect (aircraft: 3-5, quadrotor: 4-6)");
+        if (!(limits->u_min[pol.dt_row] > 0.f)) return fail(AC_ERR_BAD_ARG, "the time row's lower bound (dt_bounds[0]) must be > 0");
+    }
     const long Bout = B * n_alpha;
     if (h->dp.p.model_kind == AC_MODEL_NN) {
         if (!h->use_mfma) {

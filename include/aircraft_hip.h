@@ -247,6 +247,13 @@ typedef struct ac_ilqr_cost {
     float x_ref[13], x_goal[13];
     float u_min[7], u_max[7];  /* control box (aileron/elevator/rudder limits, control/aircraft.py:29-41) */
     float reg;                 /* Levenberg term on Quu */
+    float u_lin[7];            /* + sum_k u_lin . u_k: linear control cost (w_time on the time row: the reference's time loss,
+                                  main/control/control.py:44, 66-67) */
+    int dt_row;                /* <= 0: fixed time.  r > 0: time is a decision variable per node (control/base.py:276, 339-385:
+                                  dt_k = 1/progress_k^2 or progress_k^2, bounded by dt_bounds): control row dt_row — one the force
+                                  model ignores (aircraft 3-5, quadrotor 4-6) — carries dt_k; u_min/u_max[dt_row] are dt_bounds
+                                  (lower > 0).  The policy rollout integrates node k with the clipped u_k[dt_row]; the caller
+                                  linearises with dt_per_unit = that row and puts c = dF/d(dt) into column dt_row of Bm. */
 } ac_ilqr_cost;
 
 /* Backward (Riccati) pass along X [H+1][13][B], U [H][7][B] with A [H][13][13][B], Bm [H][13][7][B] from

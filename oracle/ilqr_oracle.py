@@ -12,12 +12,18 @@ def cost(c, X, U, node=None):
     if node is not None:
         nq, nx, ng = (np.tile(a, (1, 1, X.shape[2] // a.shape[2])) for a in node)
         d = X - nx
-        return (0.5 * nq * d * d + ng * X).sum(axis=(0, 1)) + 0.5 * (np.asarray(c.r)[None, :, None] * U * U).sum(axis=(0, 1))
+        return (0.5 * nq * d * d + ng * X).sum(axis=(0, 1)) + 0.5 * (np.asarray(c.r)[None, :, None] * U * U).sum(axis=(0, 1)) + \
+            (_u_lin(c)[None, :, None] * U).sum(axis=(0, 1))
     q, qf, r = np.asarray(c.q), np.asarray(c.qf), np.asarray(c.r)
     dx = X[:-1] - np.asarray(c.x_ref)[None, :, None]
     dg = X[-1] - np.asarray(c.x_goal)[:, None]
     return 0.5 * (q[None, :, None] * dx * dx).sum(axis=(0, 1)) + 0.5 * (r[None, :, None] * U * U).sum(axis=(0, 1)) + \
-        0.5 * (qf[:, None] * dg * dg).sum(axis=0)
+        0.5 * (qf[:, None] * dg * dg).sum(axis=0) + (_u_lin(c)[None, :, None] * U).sum(axis=(0, 1))
+
+
+def _u_lin(c):
+    """linear control cost (the time term w_time * dt_k on the time row); absent on older cost objects"""
+    return np.asarray(getattr(c, "u_lin", [0.0] * 7), dtype=np.float64)
 
 
 def costate(c, X, A, node=None):
@@ -55,7 +61,7 @@ def backward(c, X, U, A, Bm, node=None, Hz=None):
             Vx = node[0][H, :, b] * (X[H, :, b] - node[1][H, :, b]) + node[2][H, :, b]; Vxx = np.diag(node[0][H, :, b])
         for k in range(H - 1, -1, -1):
             Ak, Bk = A[k, :, :, b], Bm[k, :, :, b]
-            lx = q * (X[k, :, b] - np.asarray(c.x_ref)); lu = r * U[k, :, b]
+            lx = q * (X[k, :, b] - np.asarray(c.x_ref)); lu = r * U[k, :, b] + _u_lin(c)
             if node is not None:
                 q = node[0][k, :, b]
                 lx = q * (X[k, :, b] - node[1][k, :, b]) + node[2][k, :, b]
@@ -89,7 +95,8 @@ def forward(orc, c, x0, Xnom, U, K, kff, alphas, dt):
             u = U[k] + al * kff[k] + np.einsum("imb,mb->ib", K[k], dx)
             u = np.clip(u, umin, umax)
             Uc[k, :, sl] = u
-            x = orc.state_update(x, u, dt)
+            row = getattr(c, "dt_row", 0)
+            x = orc.state_update(x, u, u[row] if row > 0 else dt)  # time as a decision variable: node k's own (clipped) step
             Xc[k + 1, :, sl] = x
     return Xc, Uc
 

@@ -371,3 +371,81 @@ def test_envelope_penalty_steers_the_solve(gpu):
     # penalised (quadratic penalty, weight 2e6: measured median 1.06 x the bound, 0.126 / 0.088 rad at 2e4 / 2e5)
     assert (res[2e6] < 1.15 * lim).mean() > 0.9
     assert np.median(res[2e6]) < 0.5 * np.median(res[0.0])
+
+
+@pytest.mark.parametrize("model,hidden", [("poly", None), ("nn", (64, 64, 64))])
+def test_time_as_a_decision_variable_kernels_match_numpy(gpu, model, hidden):
+    """The reference carries dt_k per node as a decision variable (control/base.py:276, 339-385: dt_k = 1/progress_k^2 or
+    progress_k^2, bounded by dt_bounds) and charges the total time (main/control/control.py:44, 66-67).  Here a control row the
+    force model ignores carries dt_k: linearisation at per-node steps with c = dF/d(dt) as that row's column of B, the linear
+    time cost in the backward pass and the cost kernel, and the policy rollout that integrates node k with its own clipped
+    step — against the NumPy restatement (which takes node k's step from the same row)."""
+    import torch
+    import ilqr_oracle as io
+    from aircraft_amd.control import ILQR
+
+    ac, il0, cost, X0, U = setup(gpu, model, hidden, B=20, H=25)
+    il = ILQR(system=ac, dt=0.01, num_nodes=25, cost=cost, alphas=(1.0, 0.5, 0.1), time="variable",
+              dt_bounds=(0.006, 0.015), w_time=300.0, r_time=50.0)
+    row = il.time_row
+    assert row == 3 and il.cost.dt_row == 3 and il.cost.u_lin[3] == 300.0
+    rng = np.random.default_rng(4)
+    U = U.copy(); U[:, row] = f32_exact(rng.uniform(0.007, 0.014, (25, 20)))   # a different step at every node
+    Ud = dev(U, gpu)
+    # the nominal trajectory at those steps: the policy rollout with zero gains
+    z = lambda *s: torch.zeros(s, device=gpu)  # noqa: E731
+    X, U1 = il.forward(dev(X0, gpu), z(26, 13, 20), Ud, z(25, 7, 13, 20), z(25, 7, 20), alphas=[0.0])
+    assert torch.equal(U1, Ud)
+    f64 = lambda t: t.cpu().numpy().astype(np.float64)  # noqa: E731
+    orc = make_oracle(ac)
+    Xr = np.zeros((26, 13, 20)); Xr[0] = X0
+    for k in range(25):
+        Xr[k + 1] = orc.state_update(Xr[k], U[k], U[k, row])
+    assert block_rel_err(f64(X), Xr) < 1e-5
+    # linearisation at the nodes' own steps; the time row's column of B is c
+    ws = il._workspace(20, X.device)
+    ws["dt"].copy_(Ud[:, row, :])
+    F, A, Bm, c = il.linearise(X, Ud, dt=ws["dt"], want_c=True)
+    flatX = np.ascontiguousarray(f64(X)[:25].transpose(1, 0, 2).reshape(13, -1)); flatU = np.ascontiguousarray(U.transpose(1, 0, 2).reshape(7, -1))
+    _, Ar, Br, cr = orc.step_sens(flatX, flatU, np.ascontiguousarray(U[:, row].reshape(-1)))
+    assert rel_fro(f64(c).transpose(1, 0, 2).reshape(13, -1), cr) < 1e-5 and not f64(Bm)[:, :, row].any()
+    Bm[:, :, row, :].copy_(c)
+    K, kff, dV = il.backward(X, Ud, A, Bm)
+    Kr, kr, dVr = io.backward(il.cost, f64(X), U, f64(A), f64(Bm))
+    assert rel_fro(f64(K), Kr) < 2e-3 and rel_fro(f64(kff), kr) < 2e-3 and rel_fro(f64(dV), dVr) < 2e-3
+    assert np.abs(f64(K)[:, row]).max() > 0 and np.abs(f64(kff)[:, row]).max() > 0     # the time row takes part in the policy
+    Xc, Uc = il.forward(dev(X0, gpu), X, Ud, K, kff)
+    Xcr, Ucr = io.forward(orc, il.cost, X0, f64(X), U, f64(K), f64(kff), il.alphas, 0.01)
+    assert np.abs(f64(Uc)[:, :3] - Ucr[:, :3]).max() < 2e-4 and np.abs(f64(Uc)[:, row] - Ucr[:, row]).max() < 2e-7
+    assert (f64(Uc)[:, row] >= 0.006 - 1e-9).all() and (f64(Uc)[:, row] <= 0.015 + 1e-9).all()   # dt_bounds are a hard box
+    assert block_rel_err(f64(Xc), Xcr) < 1e-5
+    Jc = il.trajectory_cost(Xc, Uc).cpu().numpy()
+    assert np.abs(Jc - io.cost(il.cost, f64(Xc), f64(Uc))).max() / np.abs(Jc).max() < 1e-5
+
+
+def test_time_as_a_decision_variable_reaches_a_goal_the_fixed_step_cannot(gpu):
+    """Gliders at 50-65 m/s, 40 nodes, a goal 30 m ahead: at the fixed step 0.01 s the horizon covers 20-26 m, so the goal term
+    stays large; with dt_k free in [0.005, 0.02] (and the total time charged) the solve stretches the steps until the horizon
+    reaches the goal — the column c = dF/d(dt) of the sensitivity kernels is what tells it how."""
+    from aircraft_amd.control import ILQR, QuadraticCost
+
+    ac, il0, cost, X0, U = setup(gpu, "poly", None, B=48, H=40)
+    cost = QuadraticCost.goal((30.0, 0.0), w_goal=1.0, height=-200.0, w_height=1.0, w_lateral_speed=0.1, r=0.5, reg=1.0)
+    out = {}
+    for mode in ("fixed", "variable"):
+        il = ILQR(system=ac, dt=0.01, num_nodes=40, cost=cost, alphas=(1.0, 0.5, 0.25, 0.1), time=mode,
+                  dt_bounds=(0.005, 0.02), w_time=5.0, r_time=0.0)
+        X, Uo, hist = il.solve(dev(X0, gpu), dev(np.zeros_like(U), gpu), iters=12)
+        h = hist.cpu().numpy()
+        assert np.isfinite(h).all() and (np.diff(h, axis=0) <= 1e-5 * np.abs(h[:-1]) + 1e-5).all()
+        miss = (X[-1, 0] - 30.0).abs().cpu().numpy()
+        T = Uo[:, 3].sum(dim=0).cpu().numpy() if mode == "variable" else np.full(48, 0.4)
+        out[mode] = (miss, T, Uo[:, 3].cpu().numpy())
+    from tests.helpers import parity_report
+    parity_report("time_variable_vs_fixed", miss_fixed_median_m=float(np.median(out["fixed"][0])),
+                  miss_variable_median_m=float(np.median(out["variable"][0])), total_time_median_s=float(np.median(out["variable"][1])))
+    assert np.median(out["fixed"][0]) > 4.0                                  # 30 m is out of reach in 0.4 s
+    assert np.median(out["variable"][0]) < 0.25 * np.median(out["fixed"][0])  # the free steps close most of the gap
+    assert (out["variable"][1] > 0.42).mean() > 0.9                          # by taking longer ...
+    dtv = out["variable"][2]
+    assert dtv.min() >= 0.005 - 1e-9 and dtv.max() <= 0.02 + 1e-9            # ... inside dt_bounds

@@ -26,7 +26,8 @@ def test_cost_struct_layout_and_goal_helper():
 
     c = QuadraticCost.goal((150.0, 0.0), height=-200.0)
     s = c.struct()
-    assert ctypes.sizeof(s) == (13 + 13 + 7 + 13 + 13 + 7 + 7 + 1) * 4
+    assert ctypes.sizeof(s) == (13 + 13 + 7 + 13 + 13 + 7 + 7 + 1 + 7 + 1) * 4  # ... + u_lin[7], dt_row
+    assert s.dt_row == 0 and not any(s.u_lin)                                      # fixed time, no linear control cost
     assert s.qf[0] == 2000.0 and s.x_goal[0] == 150.0 and s.x_goal[2] == -200.0 and s.u_max[6] == 1.0
     X = np.zeros((3, 13, 2)); X[-1, 0] = [150.0, 149.0]; X[-1, 2] = -200.0
     U = np.zeros((2, 7, 2))
