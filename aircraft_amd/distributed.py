@@ -87,12 +87,14 @@ def unpack_records(rec, H: int):
     return rec[:, 0], rec[:, 1 : 1 + nx].reshape(n, H + 1, 13), rec[:, 1 + nx :].reshape(n, H, 7)
 
 
-def all_gather_records(rec, group=None):
-    """ONE all-gather of the per-rank record block (k, R) -> (world*k, R); identity when not distributed."""
+def all_gather_records(rec, group=None, single_rank_collective: bool = False):
+    """ONE all-gather of the per-rank record block (k, R) -> (world*k, R); identity when not distributed.
+    single_rank_collective: issue the collective even in a one-rank group (the identity then) — how the GPU test-suite runs
+    the RCCL branch on a one-GPU box."""
     torch = _torch()
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not single_rank_collective):
         return rec
     world = dist.get_world_size(group)
     if rec.is_cuda and dist.get_backend(group) == "gloo":  # gloo rehearsal of the GPU path: stage through the host

@@ -163,6 +163,37 @@ def test_line_search_accept_kernel(gpu, B, H, na):
     assert np.array_equal(X.cpu().numpy(), wX) and np.array_equal(U.cpu().numpy(), wU)
 
 
+def test_rccl_branch_of_the_record_exchange_on_one_rank(gpu):
+    """The `nccl` (= RCCL) branch of all_gather_records — the only branch an 8-GPU run takes — has never run on the
+    one-GPU boxes of this pool.  A one-rank RCCL group makes the collective the identity but runs the real call: device
+    tensors of the record layout through dist.all_gather_into_tensor on the RCCL backend, in a process of its own."""
+    code = """
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, RANK="0", WORLD_SIZE="1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from tests.helpers import make_aircraft
+from aircraft_amd.distributed import all_gather_records, merge_records, pack_records, unpack_records
+ac = make_aircraft("default")
+g = torch.Generator().manual_seed(3)
+H, B, k = 20, 300, 4
+X = torch.randn(H + 1, 13, B, generator=g).cuda(); U = torch.randn(H, 7, B, generator=g).cuda(); cost = torch.rand(B, generator=g).cuda()
+rec = pack_records(cost, X, U, k, system=ac)
+out = all_gather_records(rec, single_rank_collective=True)
+assert dist.get_backend() == "nccl" and out.is_cuda and out.data_ptr() != rec.data_ptr() and torch.equal(out, rec)
+c, Xb, Ub = unpack_records(merge_records(out, system=ac), H)
+order = torch.argsort(cost)[:k]
+assert torch.equal(c, cost[order]) and torch.equal(Xb[0], X[:, :, order[0]])
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK")
+""" % (ROOT, str(29500 + os.getpid() % 2000))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def _run_bench(extra, env_extra, timeout=600):
     env = dict(os.environ)
     env.update(env_extra)
