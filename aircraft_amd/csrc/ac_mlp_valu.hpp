@@ -926,4 +926,47 @@ __global__ __launch_bounds__(kBlock) void k_nn_rollout_tiled8(const DevParams P,
     }
 }
 
+// Closed-loop (feedback policy) rollout of this flavour: the same small-batch tile, the control of every node from the
+// solver's gains (Policy::control; every lane of an instance computes the same 7 x 13 product from the same addresses, so a
+// wave fetches each gain once).  Output instance o = a * B + b (a = line-search index), as the MFMA kernels.
+template <int WIDTH>
+__global__ __launch_bounds__(kBlock) void k_nn_rollout_policy_tiled8(const DevParams P, const ValuPlan plan,
+                                                                     const float* __restrict__ blob, const Policy pol,
+                                                                     const float* __restrict__ X0, float dt, long Bout,
+                                                                     long H, float* __restrict__ Xout,
+                                                                     float* __restrict__ Uout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef MlpEngineTiled8<WIDTH, 1, kRolloutUnits<WIDTH>> Engine;
+    Engine eng(plan, blob, smem);
+    eng.load_weights();
+    const long raw = ((long)blockIdx.x * (kBlock >> 6) + (threadIdx.x >> 6)) * Engine::kUnits + eng.unit;
+    const bool live = raw < Bout, writer = live && eng.tj == 0;
+    const long o = live ? raw : Bout - 1;
+    float x[13], u[7];
+    load_rows<13>(X0, pol.B, o % pol.B, x);
+    double xa[13];
+#pragma unroll
+    for (int r = 0; r < 13; ++r) xa[r] = (double)x[r];
+    if (writer) {
+#pragma unroll
+        for (int r = 0; r < 13; ++r) Xout[(long)r * Bout + o] = x[r];
+    }
+    MlpCoeffs<Engine> coeffs(eng);
+    for (long k = 0; k < H; ++k) {
+#pragma unroll
+        for (int r = 0; r < 13; ++r) x[r] = (float)xa[r];
+        pol.control(k, o, x, u);
+        if (writer) {
+#pragma unroll
+            for (int r = 0; r < 7; ++r) Uout[(k * 7 + r) * Bout + o] = u[r];
+        }
+        state_update_carry(P, coeffs, xa, u, pol.step(u, dt));
+        if (writer) {
+            float* out = Xout + (k + 1) * 13 * Bout;
+#pragma unroll
+            for (int r = 0; r < 13; ++r) out[(long)r * Bout + o] = (float)xa[r];
+        }
+    }
+}
+
 }  // namespace ac

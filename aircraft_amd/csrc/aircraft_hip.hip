@@ -1425,8 +1425,25 @@ int ac_rollout_policy_f32(ac_handle* h, const ac_ilqr_cost* limits, const float*
     const long Bout = B * n_alpha;
     if (h->dp.p.model_kind == AC_MODEL_NN) {
         if (!h->use_mfma) {
-            snprintf(g_err, sizeof(g_err), "policy rollout through the MLP needs the MFMA path");
-            return AC_ERR_UNSUPPORTED;
+            if (!h->has_vplan) return fail(AC_ERR_UNSUPPORTED, "policy rollout through the MLP with the MFMA path off needs hidden width 32 or 64");
+            const long roll_units = h->vwidth == 64 ? kRolloutUnits<64> : kRolloutUnits<32>;
+            const int grid = (int)((Bout + 4 * roll_units - 1) / (4 * roll_units));
+            const int lds = h->vplan.image_floats * 4 + 4 * (int)roll_units * (h->vwidth + 4) * 4;
+            bool launched = false;
+#define AC_TILED_POL8(W_)                                                                                          \
+            if (h->vwidth == W_) {                                                                                 \
+                auto kern = k_nn_rollout_policy_tiled8<W_>;                                                        \
+                int rc_ = set_lds_limit(h, kern, lds);                                                             \
+                if (rc_ != AC_OK) return rc_;                                                                      \
+                hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->vplan, h->d_vblob, pol, X0, dt, Bout, H, Xout, Uout); \
+                launched = true;                                                                                   \
+            }
+            AC_TILED_POL8(32) AC_TILED_POL8(64)
+#undef AC_TILED_POL8
+            if (!launched) return fail(AC_ERR_UNSUPPORTED, "no tiled vector-ALU kernel instance for this hidden width");
+            note_launch(h, "k_nn_rollout_policy_tiled8", grid, kBlock, lds);
+            AC_HIP(hipGetLastError());
+            return AC_OK;
         }
         const int grid = (int)((Bout + 15) / 16);
         bool launched = false;

@@ -92,9 +92,9 @@ int ac_set_params(ac_handle* h, const ac_params* params);
  *         1 tanh after layer l; widths[0] must be 5, widths[n_layers] must be 6; input/output scalers as in
  *         ScaledModel (surrogates/models.py:101-155).  use_mfma = 1: the v_mfma_f32_16x16x4_f32 engines.  use_mfma = 0
  *         ("MFMA off", BASELINE configs[1]): the register-tiled v_pk_fma_f32 engine on the vector ALUs for hidden widths
- *         <= 64 and at least two layers after the fold (step, derivative, getters, rollout, step + sensitivities, df/dx);
- *         wider nets, single-layer nets, the second-order path and the policy rollout of this flavour use the cross-lane
- *         validation form or are refused (see the entry points).
+ *         <= 64 and at least two layers after the fold (step, derivative, getters, rollout, policy rollout, step +
+ *         sensitivities, df/dx); wider nets, single-layer nets and the second-order path of this flavour use the
+ *         cross-lane validation form or are refused (see the entry points).
  *         An activation-free layer that is not the last is folded into its successor on the host, in float64
  *         (W2 (W1 x + b1) + b2 = (W2 W1) x + W2 b1 + b2): the reference checkpoint's Linear-Linear-Tanh-Linear net
  *         (surrogates/models.py:114-123) runs as 5-32-6.  Same function, fewer layers; results differ from a
@@ -265,7 +265,8 @@ int ac_ilqr_cost_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* X, con
                      float* out, void* stream);
 /* Closed-loop rollout with a parallel line search: output instance o = a*B + b uses step alphas[a] (HOST array,
  * n_alpha <= 8):  u = clip(U_k[b] + alpha kff_k[b] + K_k[b] (x - Xnom_k[b])),  x+ = F(x, u, dt).
- * X0 [13][B]; Xout [H+1][13][n_alpha*B]; Uout [H][7][n_alpha*B]. */
+ * X0 [13][B]; Xout [H+1][13][n_alpha*B]; Uout [H][7][n_alpha*B].  MLP with use_mfma = 0: hidden widths 32 and 64
+ * (AC_ERR_UNSUPPORTED otherwise). */
 int ac_rollout_policy_f32(ac_handle* h, const ac_ilqr_cost* limits, const float* X0, const float* Xnom,
                           const float* U, const float* K, const float* kff, const float* alphas, int n_alpha, float dt,
                           long B, long H, float* Xout, float* Uout, void* stream);

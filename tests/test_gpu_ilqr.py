@@ -13,13 +13,13 @@ def dev(a, gpu):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(gpu)
 
 
-def setup(gpu, model="poly", hidden=None, B=24, H=30):
+def setup(gpu, model="poly", hidden=None, B=24, H=30, use_mfma=True):
     """B gliders released near trim from the same point, flying roughly along +x; the goal is a point a little to the
     side of where they would coast to, so the optimal controls are small and the closed loop stays in the envelope."""
     from aircraft_amd.control import ILQR, QuadraticCost
     from aircraft_amd.synthetic import quat_from_euler, quat_rotate
 
-    ac = make_aircraft(model, hidden=hidden)
+    ac = make_aircraft(model, hidden=hidden, use_mfma=use_mfma)
     T = H * 0.01
     cost = QuadraticCost.goal((60.0 * T, 0.5), w_goal=1.0, height=-200.0, w_height=1.0, w_lateral_speed=0.5, r=0.5, reg=1.0)
     cost.q = [0, 0, 1e-2, 0, 0, 0, 0, 0, 0, 0, 0.2, 0.2, 0.2]
@@ -52,11 +52,12 @@ def test_backward_pass_matches_numpy(gpu, model, hidden):
     assert (dV.cpu().numpy()[0] <= 0).all()  # descent direction
 
 
-@pytest.mark.parametrize("model,hidden", [("poly", None), ("nn", (64, 64, 64))])
-def test_policy_rollout_and_cost_match_numpy(gpu, model, hidden):
+@pytest.mark.parametrize("model,hidden,use_mfma", [("poly", None, True), ("nn", (64, 64, 64), True),
+                                                   ("nn", (64, 64, 64), False), ("nn", (32, 32), False)])
+def test_policy_rollout_and_cost_match_numpy(gpu, model, hidden, use_mfma):
     import ilqr_oracle as io
 
-    ac, il, cost, X0, U = setup(gpu, model, hidden, B=20, H=25)
+    ac, il, cost, X0, U = setup(gpu, model, hidden, B=20, H=25, use_mfma=use_mfma)
     Ud = dev(U, gpu)
     X = il.rollout(dev(X0, gpu), Ud)
     F, A, Bm, _ = il.linearise(X, Ud, want_c=False)
@@ -74,11 +75,12 @@ def test_policy_rollout_and_cost_match_numpy(gpu, model, hidden):
     assert block_rel_err(X0c.cpu().numpy(), X.cpu().numpy()) < 1e-6
 
 
-@pytest.mark.parametrize("model,hidden,B", [("poly", None, 256), ("nn", (128, 128, 128, 128), 128)])
-def test_ilqr_cost_decreases(gpu, model, hidden, B):
+@pytest.mark.parametrize("model,hidden,B,use_mfma", [("poly", None, 256, True), ("nn", (128, 128, 128, 128), 128, True),
+                                                     ("nn", (64, 64, 64), 300, False)])
+def test_ilqr_cost_decreases(gpu, model, hidden, B, use_mfma):
     import torch
 
-    ac, il, cost, X0, U = setup(gpu, model, hidden, B=B, H=50)
+    ac, il, cost, X0, U = setup(gpu, model, hidden, B=B, H=50, use_mfma=use_mfma)
     X, Uo, hist = il.solve(dev(X0, gpu), dev(np.zeros_like(U), gpu), iters=6)
     h = hist.cpu().numpy()
     assert np.isfinite(h).all()
