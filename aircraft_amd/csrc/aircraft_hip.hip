@@ -16,6 +16,7 @@
 #include "ac_track.hpp"
 #include "ac_hess.hpp"
 #include "ac_hess_nn.hpp"
+#include "ac_hess_rev.hpp"
 #include "ac_select.hpp"
 
 using namespace ac;
@@ -72,6 +73,11 @@ struct ac_handle {
     bool has_linear, has_poly, has_mlp;
     MlpPlan plan;
     MlpPlan plan_sens;  // the MFMA sensitivity engines' plan: last layer = [bias][wlt] for MlpEngine::last_valu (ac_set_mlp)
+    MlpPlan plan_rev;   // width 128 on the matrix cores, <= 3 hidden products: plan_sens + the TRANSPOSED hidden blocks for the
+    bool has_rev;       // reverse sweep of k_nn_stage_tensors_rev (ac_hess_rev.hpp); rev_layers = layers of the net itself
+    int rev_layers;
+    float* d_rev_scratch;  // per-wave layer states of that kernel (ac_reserve_hess_workspace)
+    size_t rev_scratch_floats;
     int wt;         // register tiles per slab the plan needs (2, 4 or 8)
     int use_mfma;
     float* d_blob;  // packed MLP weights + biases (device)
@@ -263,6 +269,7 @@ int ac_destroy(ac_handle* h) {
     if (h->d_track) (void)hipFree(h->d_track);
     if (h->d_hess_ws) (void)hipFree(h->d_hess_ws);
     if (h->d_hess_ws2) (void)hipFree(h->d_hess_ws2);
+    if (h->d_rev_scratch) (void)hipFree(h->d_rev_scratch);
     delete h;
     return AC_OK;
 }
@@ -369,8 +376,30 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
         // plan_sens (below) copies [bias][wlt] to LDS, `pl` the fragments and the bias as before
         if (l == n_layers - 1 && n_layers > 1) total_floats += (size_t)wlt_bytes / 4;
     }
+    // Width 128 on the matrix cores with one to three hidden products: the transposed hidden blocks of the reverse sweep
+    // (k_nn_stage_tensors_rev), top hidden layer first, behind the net's own blocks.
+    const int n_hid = n_layers - 2;
+    const bool want_rev = use_mfma && wt == 8 && n_hid >= 1 && n_layers + n_hid <= AC_MAX_LAYERS;
+    size_t rev_off[AC_MAX_LAYERS] = {0};
+    const size_t rev_block_floats = (size_t)wt * wt * 256 + 256;  // fragments + a (zero) bias piece: the hidden blocks' size class
+    if (want_rev)
+        for (int i = 0; i < n_hid; ++i) { rev_off[i] = total_floats; total_floats += rev_block_floats; }
     // Pack: [nt][kt][lane][4] with lane = col + 16 g -> W[16 nt + col][16 kt + 4 g + j]; then the padded bias.
     std::vector<float> blob(total_floats, 0.f);
+    if (want_rev)
+        for (int i = 0; i < n_hid; ++i) {
+            const int l = n_hid - i;  // forward layer l: h_l (nin) -> h_{l+1} (nout); the block multiplies by its transpose
+            const int nin = widths[l], nout = widths[l + 1];
+            float* dst = blob.data() + rev_off[i];
+            for (int nt = 0; nt < wt; ++nt)
+                for (int kt = 0; kt < wt; ++kt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j) {
+                            const int row = 16 * nt + (lane & 15), k = 16 * kt + 4 * (lane >> 4) + j;
+                            dst[((size_t)(nt * wt + kt) * 64 + lane) * 4 + j] =
+                                (row < nin && k < nout) ? fW[(size_t)l][(size_t)k * nin + row] : 0.f;
+                        }
+        }
     for (int l = 0; l < n_layers; ++l) {
         const int nin = widths[l], nout = widths[l + 1], KT = pl.KT[l], NT = pl.NT[l];
         float* dst = blob.data() + pl.g_off[l];
@@ -404,6 +433,7 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
     }
     // LDS plan: everything resident if it fits; otherwise the largest layers stream through a 2-slot ring.
     auto plan_lds = [&](MlpPlan& pl) -> int {
+        const int n_layers = pl.n_layers;  // (plan_rev carries more blocks than the net has layers)
         pl.n_streamed = 0; pl.first_streamed = -1;
         int total = 0;
         for (int l = 0; l < n_layers; ++l) total += pl.bytes[l];
@@ -447,6 +477,19 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
         ps.bytes[last] = 1024 + wlt_bytes;
         const int rc = plan_lds(ps);
         if (rc != AC_OK) return rc;
+    }
+    MlpPlan pr = ps;
+    bool rev_ok = false;
+    if (want_rev) {
+        for (int i = 0; i < n_hid; ++i) {
+            const int e = n_layers + i;
+            pr.KT[e] = wt; pr.NT[e] = wt; pr.act[e] = 0;
+            pr.g_off[e] = (int)rev_off[i];
+            pr.bytes[e] = (int)(rev_block_floats * 4);
+        }
+        pr.n_layers = n_layers + n_hid;
+        // the kernel expects the hidden and the transposed blocks to stream (one size class) and the edge blocks to stay
+        rev_ok = plan_lds(pr) == AC_OK && pr.n_streamed == 2 * n_hid && pr.lds_off[0] >= 0 && pr.lds_off[n_layers - 1] >= 0;
     }
     // "MFMA off": weight image of the tiled vector-ALU engine, k-major [K][N] per layer (the last layer transposed [8][K]),
     // hidden widths zero-padded to 32 or 64.  Nets it does not cover (wider than 64, or a single layer after the fold)
@@ -506,6 +549,9 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
     h->blob_floats = total_floats;
     h->plan = pl;
     h->plan_sens = ps;
+    h->plan_rev = pr;
+    h->has_rev = rev_ok;
+    h->rev_layers = n_layers;
     h->wt = wt;
     h->use_mfma = use_mfma ? 1 : 0;
     memcpy(h->dp.mlp_in_mean, in_mean, 5 * sizeof(float));
@@ -1036,6 +1082,11 @@ int ac_quat_rows_f32(ac_handle* h, int mode, const float* X, const float* Xdot, 
 }
 
 // ---- second-order step sensitivities ---------------------------------------------------------------
+// persistent grid of k_nn_stage_tensors_rev: one workgroup per CU at most (its weight plan fills the LDS)
+static int rev_grid(const ac_handle* h, long n) {
+    const long tasks = (n + 63) / 64, cus = h->num_cus > 0 ? h->num_cus : 256;
+    return (int)(tasks < cus ? tasks : cus);
+}
 // One RK4 sub-step's second-order block with the handle's CURRENT parameters (the caller sets substeps = 1).
 static int hess_single(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, const float* Lam,
                        long n, long blk, float* Hout, hipStream_t st) {
@@ -1049,6 +1100,22 @@ static int hess_single(ac_handle* h, const float* X, const float* U, float dt, c
             return fail(AC_ERR_WORKSPACE, "second-order workspace too small: call ac_reserve_hess_workspace(h, n) first");
         const int grid_t = (int)((n + 63) / 64);
         bool launched = false;
+#ifndef AC_NO_HESS_REV
+        if (h->has_rev && h->use_mfma && h->wt == 8) {
+            // width 128: forward tangents + reverse sweep (12 slab-layer products per hidden layer instead of 29), persistent grid
+            const int grid_r = rev_grid(h, n);
+            const size_t need_r = (size_t)grid_r * (kBlock / 64) * (size_t)rev_scratch_f32x4(h->wt, h->rev_layers - 2) * 4;
+            if (need_r > h->rev_scratch_floats)
+                return fail(AC_ERR_WORKSPACE, "second-order workspace too small: call ac_reserve_hess_workspace(h, n) first");
+            auto kern = k_nn_stage_tensors_rev<8>;
+            int rc_ = set_lds_limit(h, kern, h->plan_rev.lds_total);
+            if (rc_ != AC_OK) return rc_;
+            hipLaunchKernelGGL(kern, grid_r, kBlock, h->plan_rev.lds_total, st, h->dp, h->plan_rev, h->d_blob, X, U, dt, dt_per_unit,
+                               n, blk, h->rev_layers, h->d_rev_scratch, h->d_hess_ws);
+            note_launch(h, "k_nn_stage_tensors_rev", grid_r, kBlock, h->plan_rev.lds_total);
+            launched = true;
+        } else {
+#endif
         AC_NN_CASE(2, true, (k_nn_stage_tensors<2, true, 0>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
         AC_NN_CASE(4, true, (k_nn_stage_tensors<4, true, 0>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
         AC_NN_CASE(8, true, (k_nn_stage_tensors<8, true, 0>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
@@ -1056,6 +1123,9 @@ static int hess_single(ac_handle* h, const float* X, const float* U, float dt, c
         AC_NN_CASE(4, false, (k_nn_stage_tensors<4, false, 0>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
         // width 128 on the matrix cores: the cross pairs between inputs {0, 1} and {3, 4} come from a second launch
         AC_NN_CASE(8, true, (k_nn_stage_tensors<8, true, 1>), grid_t, kBlock, X, U, dt, dt_per_unit, n, blk, h->d_hess_ws)
+#ifndef AC_NO_HESS_REV
+        }
+#endif
         if (!launched) return fail(AC_ERR_UNSUPPORTED, "second-order blocks at width > 64 need the MFMA path (use_mfma = 1)");
         AC_HIP(hipGetLastError());
         launch_hess<AC_MODEL_NN>(h, st, X, U, dt, dt_per_unit, Lam, n, blk, Hout, &grid);
@@ -1162,6 +1232,15 @@ int ac_reserve_hess_workspace(ac_handle* h, long n) {
         h->d_hess_ws = nullptr; h->hess_ws_floats = 0;
         AC_HIP(hipMalloc((void**)&h->d_hess_ws, need * sizeof(float)));
         h->hess_ws_floats = need;
+    }
+    if (h->has_rev && n > 0) {  // the reverse-sweep kernel's layer states: one slot per wave of a persistent grid
+        const size_t need_r = (size_t)rev_grid(h, n) * (kBlock / 64) * (size_t)rev_scratch_f32x4(h->wt, h->rev_layers - 2) * 4;
+        if (need_r > h->rev_scratch_floats) {
+            if (h->d_rev_scratch) (void)hipFree(h->d_rev_scratch);
+            h->d_rev_scratch = nullptr; h->rev_scratch_floats = 0;
+            AC_HIP(hipMalloc((void**)&h->d_rev_scratch, need_r * sizeof(float)));
+            h->rev_scratch_floats = need_r;
+        }
     }
     const size_t need2 = (size_t)n * hess_compose_floats(h->dp.p.substeps);  // sized for the handle's CURRENT sub-step count
     if (need2 > h->hess_ws2_floats) {
