@@ -283,3 +283,47 @@ def test_hessian_composed_over_substeps(gpu, model, hidden, substeps, normalise)
     Hs = ms.hessian(Xs, Us, Ls)
     flat = ac.step_hess(dev(X[:, : 7 * B], gpu), dev(U[:, : 7 * B], gpu), dt, dev(lam[:, : 7 * B], gpu))
     assert torch.allclose(Hs.permute(1, 2, 0, 3).reshape(21, 21, 7 * B), flat, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("hidden,act_last,n,kernel", [
+    ((128, 128, 128, 128), 0, 333, "rev"),   # three hidden products: the cfg3 net, ragged batch (5 full tasks + 13 units)
+    ((128, 128, 128, 128), 1, 70, "rev"),    # tanh on the LAST layer as well: R_top carries act'(p), + act''(p) J J
+    ((100, 128, 90), 0, 64, "rev"),          # two hidden products, widths below the padded 128
+    ((128, 128, 128, 128), 0, 7, "rev"),     # fewer units than one wave
+    ((128, 128), 0, 96, "slabs"),            # one hidden product: the whole plan is resident, the slab-per-derivative kernel stays
+    ((128, 128, 128, 128, 128), 0, 96, "slabs"),  # four hidden products: more blocks than the reverse plan holds
+])
+def test_width_128_stage_tensors_by_reverse_sweep(gpu, hidden, act_last, n, kernel):
+    """Width 128 on the matrix cores: the stage tensors come from k_nn_stage_tensors_rev (forward tangents, reverse sweep through
+    the transposed hidden blocks, per-unit contraction; ac_hess_rev.hpp) for nets with two or three hidden products, from the
+    slab-per-derivative kernel otherwise; both against central differences of the oracle's exact float64 Jacobians."""
+    import torch
+
+    from aircraft_amd import Aircraft, AircraftConfiguration, AircraftOpts, MlpData
+    from tests.helpers import GLIDER
+
+    base = MlpData.synthetic(hidden, seed=17)
+    acts = [1] * len(hidden) + [act_last]
+    md = MlpData(base.weights, base.biases, acts, base.input_mean, base.input_std, base.output_mean, base.output_std)
+    ac = Aircraft(AircraftOpts(coeff_model_type="nn", coeff_model_path=md, aircraft_config=AircraftConfiguration(dict(GLIDER)),
+                               physical_integration_substeps=1))
+    ac.normalise = True
+    orc = make_oracle(ac)
+    X, U, lam = units(n, seed=71)
+    Xd, Ud, Ld = dev(X, gpu), dev(U, gpu), dev(lam, gpu)
+    Hm = ac.step_hess(Xd, Ud, 0.01, Ld)
+    torch.cuda.synchronize()
+    Hh = Hm.cpu().numpy().astype(np.float64)
+    m = min(n, 48)
+    want = oracle_step_hessian(orc, X[:, :m], U[:, :m], 0.01, lam[:, :m])
+    assert np.isfinite(Hh).all()
+    assert rel_block(Hh[:, :, :m], want) < 5e-4
+    assert np.abs(Hh - Hh.transpose(1, 0, 2)).max() <= 2e-5 * np.abs(Hh).max()
+    # same inputs twice on the same handle: identical bits (scratch slots, ring position and workspace carry nothing over)
+    H2 = ac.step_hess(Xd, Ud, 0.01, Ld)
+    assert torch.equal(Hm, H2)
+    # a unit's block does not depend on its position in the batch or on its neighbours (scratch slots are per wave)
+    perm = torch.randperm(n, device=gpu)
+    Hp = ac.step_hess(Xd[:, perm].contiguous(), Ud[:, perm].contiguous(), 0.01, Ld[:, perm].contiguous())
+    assert torch.equal(Hp, Hm[:, :, perm])
+    del kernel  # (documents which stage-tensor kernel the dispatcher picks: profiles/r03_hess_rev_stats.txt shows it by name)
