@@ -23,6 +23,12 @@
 
 namespace ac {
 
+#ifdef AC_REV_CLOCKS  // (measurement flavour, tools/hess_rev_phases.sh: shader-clock cycles per phase of one wave, printed)
+#define AC_REV_TICK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); clk[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define AC_REV_TICK(i) do { } while (0)
+#endif
+
 template <int WT>
 struct MlpEngineRev : MlpEngine<6, WT, true, true> {
     typedef MlpEngine<6, WT, true, true> Base;
@@ -110,14 +116,10 @@ struct MlpEngineRev : MlpEngine<6, WT, true, true> {
             }
         }
     }
-    // The accumulators must sit in architectural VGPRs while a contraction runs (every packed FMA reads and writes them) and the
-    // 192 slab registers in accumulation registers (each is read once per contraction): left alone, the allocator keeps the
-    // slabs — MFMA operands a moment ago — in the VGPRs and wraps every FMA in two v_accvgpr_read and two v_accvgpr_write.
-    AC_DI void pin(f32x2 (&acc)[3][15]) {
-#pragma unroll
-        for (int kp = 0; kp < 3; ++kp)
-#pragma unroll
-            for (int i = 0; i < 15; ++i) asm volatile("" : "+v"(acc[kp][i]));
+    // The 192 slab registers belong in the accumulation registers while a contraction runs (each is read once; the 90 sums are
+    // read and written by every packed FMA): left alone, the allocator keeps the slabs — MFMA operands a moment ago — in the
+    // VGPRs and wraps every FMA in two v_accvgpr_read and two v_accvgpr_write.
+    AC_DI void pin_slabs() {
 #pragma unroll
         for (int sl = 0; sl < 6; ++sl)
 #pragma unroll
@@ -127,14 +129,17 @@ struct MlpEngineRev : MlpEngine<6, WT, true, true> {
     }
     // act''/act' of a tanh neuron with output h, as the second-order epilogue of MlpEngine forms it: -2 h / (1 - h^2),
     // 0 for a saturated neuron (its tangents are 0 as well)
-    AC_DI static float curv_over_slope(float h, float sp) { return sp > 1e-30f ? -2.0f * h / sp : 0.f; }
+    // (v_rcp_f32, 1 ulp: an IEEE division here is 12 instructions and a branch per neuron)
+    AC_DI static float curv_over_slope(float h, float sp) { return sp > 1e-30f ? -2.0f * h * __builtin_amdgcn_rcpf(sp) : 0.f; }
 
     // Top hidden layer: its state (h, s^1..5) is in the registers; R = the rows of the last layer from the `wlt` image of
     // last_valu ([tile][lane group][6 float4] = {W(2kp, n), W(2kp+1, n), W(2kp, n+1), W(2kp+1, n+1)}, ac_set_mlp), times rs[k]
     // (act' of an activated last layer, else 1).  Leaves a[k] = R[k] . act'(a_top): the input of the first reverse product.
+    // (Routed through the scratch like the layers between — state stored, rows loaded into the slabs, contract_mid — the same
+    // code came out of the register allocator twice as slow at BOTH call sites: 24.5 ms against 19.9.)
     AC_DI void contract_top(const char* wl_last, const float (&rs)[6], f32x2 (&acc)[3][15]) {
         const f32x4* wv = reinterpret_cast<const f32x4*>(wl_last + 1024) + g * 6;
-        pin(acc);
+        pin_slabs();
 #pragma unroll
         for (int t = 0; t < WT; ++t) {
             f32x4 w[6];
@@ -164,7 +169,7 @@ struct MlpEngineRev : MlpEngine<6, WT, true, true> {
     // ([6 slabs][WT tiles][64 lanes] float4, as store_state wrote it).  Leaves a[k] = R[k] . act'.
     AC_DI void contract_mid(const f32x4* __restrict__ sl, f32x2 (&acc)[3][15]) {
         f32x4 cur[6], nxt[6];
-        pin(acc);
+        pin_slabs();
 #pragma unroll
         for (int i = 0; i < 6; ++i) cur[i] = sl[(i * WT + 0) * 64 + lane];
 #pragma unroll
@@ -186,6 +191,7 @@ struct MlpEngineRev : MlpEngine<6, WT, true, true> {
                 contract1(curv_over_slope(h, sp), s, R, acc);
 #pragma unroll
                 for (int k = 0; k < 6; ++k) a[k][t][r] = R[k >> 1][k & 1] * sp;
+                __builtin_amdgcn_sched_barrier(0);  // one neuron at a time: interleaved, four neurons' operands overflow the file
             }
 #pragma unroll
             for (int i = 0; i < 6; ++i) cur[i] = nxt[i];
@@ -196,7 +202,7 @@ struct MlpEngineRev : MlpEngine<6, WT, true, true> {
     // s^a = (1 - h^2) W0[n][a] (the transposed W0 of first_valu's block), so c s^a s^b = -2 h (1 - h^2) W0[n][a] W0[n][b].
     AC_DI void contract_bottom(const f32x4* __restrict__ sl, const char* wl0, f32x2 (&acc)[3][15]) {
         const f32x4* w0t = reinterpret_cast<const f32x4*>(wl0 + 1024);
-        pin(acc);
+        pin_slabs();
 #pragma unroll
         for (int t = 0; t < WT; ++t) {
             const f32x4 h4 = sl[t * 64 + lane];
@@ -214,9 +220,37 @@ struct MlpEngineRev : MlpEngine<6, WT, true, true> {
 #pragma unroll
                 for (int i = 0; i < 5; ++i) s[i] = w[i][r];
                 contract1(-2.0f * h * sp, s, R, acc);
+                __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    // A layer's 90 per-lane sums, reduce-scattered over the unit's four lanes and added to the lane's running totals: lane group
+    // g keeps flat entry 4 q + (0, 2, 1, 3)[g] of quad q (flat = k * 15 + ab).  Only these 23 registers — not the 90 sums —
+    // are live across the next reverse product.
+    AC_DI static void fold(const f32x2 (&acc)[3][15], float (&tot)[23]) {
+#pragma unroll
+        for (int q = 0; q < 23; ++q) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int f = 4 * q + e;
+                v[e] = f < 90 ? acc[(f / 15) >> 1][f % 15][(f / 15) & 1] : 0.f;
+            }
+            tot[q] += Base::unit_scatter4(v);
+        }
+    }
+    // values that only cross a contraction (the running totals, the stage point): into the 64 accumulation registers the slabs
+    // leave free, so the contraction's 90 sums and its operands have the vector file to themselves
+    template <int N> AC_DI static void park(float (&v)[N]) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) asm volatile("" : "+a"(v[i]));
+    }
+    AC_DI static void zero(f32x2 (&acc)[3][15]) {
+#pragma unroll
+        for (int kp = 0; kp < 3; ++kp)
+#pragma unroll
+            for (int i = 0; i < 15; ++i) acc[kp][i] = f32x2{0.f, 0.f};
     }
     // slabs [0, NS) of the state to the scratch
     template <int NS> AC_DI void store_state(f32x4* __restrict__ sl) const {
@@ -227,7 +261,7 @@ struct MlpEngineRev : MlpEngine<6, WT, true, true> {
     }
 };
 
-// float4 of scratch per wave: h_1 + the full state of the hidden layers 2 .. nh
+// float4 of scratch per wave: h_1 + the full state of the hidden layers 2 .. nh (slot l - 2 for layer l)
 constexpr long rev_scratch_f32x4(int wt, int nh) { return (long)(1 + 6 * (nh > 1 ? nh - 1 : 0)) * wt * 64; }
 
 // Persistent workgroups (one per CU: the 131 KB weight plan), task = 64 units.  `plan` = plan_rev: entries 0 .. L-1 the net as
@@ -243,12 +277,19 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors_rev(const DevPar
     MlpEngineRev<WT> eng(plan, blob, smem);
     eng.load_weights();
     const int nh = L - 2;
-    f32x4* const mine = reinterpret_cast<f32x4*>(scratch) +
-                        ((long)blockIdx.x * (kBlock >> 6) + (threadIdx.x >> 6)) * rev_scratch_f32x4(WT, nh);
+    // this wave's scratch: a wave-uniform base (scalar registers), the lane offset added by the accesses themselves
+    f32x4* const mine0 = reinterpret_cast<f32x4*>(scratch) +
+                         ((long)blockIdx.x * (kBlock >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) *
+                             rev_scratch_f32x4(WT, nh);
     const long ntasks = (n + 63) / 64;
+#ifdef AC_REV_CLOCKS
+    unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
 #pragma nounroll
     for (long task = blockIdx.x; task < ntasks; task += gridDim.x) {
-        const WaveUnit w((int)threadIdx.x, task, n, blk);
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));  // lane-dependent values are rebuilt per task, not hoisted into registers the body needs
+        const WaveUnit w(tid, task, n, blk);
         float x0[13], u[7];
         load_rows<13>(X, w.ua, x0);
         load_rows<7>(U, w.ua, u);
@@ -258,6 +299,10 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors_rev(const DevPar
         for (int i = 0; i < 13; ++i) xs[i] = x0[i];
 #pragma nounroll
         for (int s = 0; s < 4; ++s) {
+            // a copy of the scratch base the optimiser cannot see through: it otherwise hoists the ~150 tile addresses of the
+            // stage (and the 126 output addresses below: UnitAddr::late) to kernel entry and spills them
+            f32x4* mine = mine0;
+            asm volatile("" : "+s"(mine));
             AeroPre<float> ap;
             aero_pre(P, xs, ap);
             const float in[5] = {ap.qbar, ap.alpha, ap.beta, u[0], u[1]};
@@ -267,20 +312,27 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors_rev(const DevPar
             // ---- forward: value + five tangents, the states below the top hidden layer to the scratch
             const char* wl0 = eng.acquire(0);
             eng.first_valu(wl0, z);
+#ifndef AC_REV_SKIP_STORE
             eng.template store_state<1>(mine);
+#endif
 #pragma nounroll
             for (int l = 1; l <= nh; ++l) {
                 const char* wl = eng.acquire(l);
+#ifndef AC_REV_SKIP_FWD
                 eng.template layer<WT, WT, 1>(wl, 1);
+#endif
+#ifndef AC_REV_SKIP_STORE
                 if (l < nh) eng.template store_state<6>(mine + WT * 64 + (long)(l - 1) * 6 * WT * 64);
+#endif
             }
+            AC_REV_TICK(0);  // [0] stage point, first layer, hidden products, state stores
             float y[6], J[6][5];
             const char* wll = eng.acquire(L - 1);
             const int act_last = plan.act[L - 1];
             eng.template last_valu<5>(wll, act_last, y, J);
             // ---- outputs y and J from lane group 0 (J is dead afterwards)
-            float* o = out + w.ua.off(kStageFloats) + (long)s * kStageRows * blk;
             if (w.live && w.g == 0) {
+                float* o = out + w.ua.late().off(kStageFloats) + (long)s * kStageRows * blk;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     o[(long)k * blk] = y[k];
@@ -288,13 +340,19 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors_rev(const DevPar
                     for (int i = 0; i < 5; ++i) o[(long)(6 + k * 5 + i) * blk] = J[k][i];
                 }
             }
+            AC_REV_TICK(1);  // [1] last layer, y and J out
             // ---- reverse sweep with the contraction at every hidden layer
             float rs[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) rs[k] = act_last ? fmaf(-y[k], y[k], 1.0f) : 1.0f;
-            typename MlpEngineRev<WT>::f32x2 acc[3][15];
-            {   // y = tanh(p) on the last layer: + act''(p_k) dp/dz_a dp/dz_b = -2 y_k J_a J_b / act'(p_k), once per unit (the
-                // four lanes' sums are added at the end); zero otherwise
+            typedef MlpEngineRev<WT> E;
+            float tot[23];  // this lane's share of the 90 entries of T (E::fold)
+#pragma unroll
+            for (int q = 0; q < 23; ++q) tot[q] = 0.f;
+            {
+                typename E::f32x2 acc[3][15];
+                // y = tanh(p) on the last layer: + act''(p_k) dp/dz_a dp/dz_b = -2 y_k J_a J_b / act'(p_k), once per unit (lane
+                // group 0; the four lanes' sums are added by fold); zero otherwise
                 const bool fix = act_last && w.g == 0;
                 int pi = 0;
 #pragma unroll
@@ -303,41 +361,68 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors_rev(const DevPar
                     for (int j = i; j < 5; ++j, ++pi)
 #pragma unroll
                         for (int k = 0; k < 6; ++k)
-                            acc[k >> 1][pi][k & 1] = fix ? MlpEngineRev<WT>::curv_over_slope(y[k], rs[k]) * J[k][i] * J[k][j] : 0.f;
+                            acc[k >> 1][pi][k & 1] = fix ? E::curv_over_slope(y[k], rs[k]) * J[k][i] * J[k][j] : 0.f;
+                E::park(tot);
+                E::park(xs);
+#ifndef AC_REV_SKIP_CONTRACT  // (timing experiments only: tools/hess_rev_phases.sh)
+                eng.contract_top(wll, rs, acc);
+#endif
+                AC_REV_TICK(2);  // [2] top contraction
+                E::fold(acc, tot);
+                AC_REV_TICK(6);  // [6] folds
             }
-            eng.contract_top(wll, rs, acc);
 #pragma nounroll
             for (int l = nh; l >= 1; --l) {
+#ifndef AC_REV_SKIP_RAW
                 eng.layer_raw(eng.acquire(L + nh - l));
+#else
+                (void)eng.acquire(L + nh - l);
+#endif
+                AC_REV_TICK(3);  // [3] reverse products
+                typename E::f32x2 acc[3][15];
+                E::zero(acc);
+                E::park(tot);
+                E::park(xs);
+#ifndef AC_REV_SKIP_CONTRACT
                 if (l > 1) eng.contract_mid(mine + WT * 64 + (long)(l - 2) * 6 * WT * 64, acc);
                 else eng.contract_bottom(mine, wl0, acc);
+#endif
+                if (l > 1) AC_REV_TICK(4); else AC_REV_TICK(5);  // [4] contractions between, [5] bottom contraction
+                E::fold(acc, tot);
+                AC_REV_TICK(6);
             }
-            // ---- the 90 sums of T reduce-scattered over the unit's four lanes
+            // ---- T: every lane stores its 23 (lane group 0 and 1: 22 or 23) entries
+            if (w.live) {
+                float* o = out + w.ua.late().off(kStageFloats) + (long)s * kStageRows * blk;
 #pragma unroll
-            for (int q = 0; q < 23; ++q) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int f = 4 * q + e;
-                    v[e] = f < 90 ? acc[(f / 15) >> 1][f % 15][(f / 15) & 1] : 0.f;
+                for (int q = 0; q < 23; ++q) {
+                    const int f = 4 * q + (w.g == 0 ? 0 : w.g == 1 ? 2 : w.g == 2 ? 1 : 3);
+                    if (f < 90) o[(long)(36 + f) * blk] = tot[q];
                 }
-                const float tot = MlpEngineRev<WT>::unit_scatter4(v);  // lane group 0, 1, 2, 3: the total of v[0], v[2], v[1], v[3]
-                const int f = 4 * q + (w.g == 0 ? 0 : w.g == 1 ? 2 : w.g == 2 ? 1 : 3);
-                if (w.live && f < 90) o[(long)(36 + f) * blk] = tot;
             }
-            if (s < 3) {  // next primal stage point
+            if (s < 3) {  // next primal stage point.  x0, u and this stage's y are read again (y from the rows lane group 0 of this
+                          // very wave stored above): 32 registers fewer across the products, where the vector file is full
+                load_rows<13>(X, w.ua, x0);
+                load_rows<7>(U, w.ua, u);
                 GivenY prov;
+                const float* yo = out + w.ua.late().off(kStageFloats) + (long)s * kStageRows * blk;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) prov.y[k] = y[k];
+                for (int k = 0; k < 6; ++k) prov.y[k] = yo[(long)k * blk];
                 float k1[13];
                 state_derivative<float>(P, prov, xs, u, k1);
                 const float hs = h * ((s == 2) ? 1.0f : 0.5f);
 #pragma unroll
                 for (int i = 0; i < 13; ++i) xs[i] = fmaf(hs, k1[i], x0[i]);
             }
+            AC_REV_TICK(7);  // [7] T out, next stage point
         }
     }
     eng.drain();
+#ifdef AC_REV_CLOCKS
+    if ((threadIdx.x & 63) == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && threadIdx.x < 128)
+        printf("rev clocks block %d wave %d: fwd %llu last %llu top %llu raw %llu mid %llu bottom %llu fold %llu rest %llu\n", (int)blockIdx.x,
+               (int)(threadIdx.x >> 6), clk[0], clk[1], clk[2], clk[3], clk[4], clk[5], clk[6], clk[7]);
+#endif
 }
 
 }  // namespace ac
