@@ -197,7 +197,10 @@ int ac_quat_rows_f32(ac_handle* h, int mode, const float* X, const float* Xdot, 
  * (the reference's largest time sink, todo.md:102).  lambda [13][n] (device) are the multipliers of the 13 rows of F.
  * Exact second-order forward mode of the same fp32 arithmetic as ac_step_f32.  Rows/columns of p (0-2) and of controls
  * without effect are zero.  All force models.  The MLP surrogate evaluates its second-derivative tensor with the MFMA
- * engine into a handle-owned workspace of n*504 floats: size it once with ac_reserve_hess_workspace(h, n_max) — a
+ * engine (hidden width 128 with two or three hidden 128 x 128 products: forward tangents + a reverse sweep through the
+ * transposed blocks, csrc/ac_hess_rev.hpp, which also keeps per-wave layer states in a handle-owned scratch of
+ * CUs x 4 x (1 + 6 (hidden products - 1)) x 8 KiB; otherwise one slab per derivative, csrc/ac_hess_nn.hpp)
+ * into a handle-owned workspace of n*504 floats: size it once with ac_reserve_hess_workspace(h, n_max) — a
  * host-side call that may allocate — BEFORE the first compute call (and before capturing a hipGraph); the compute calls
  * themselves never allocate, free or synchronise and return AC_ERR_WORKSPACE when the workspace is too small.  The
  * workspace is one buffer per handle: second-order calls of one handle must be ordered on one stream (or use one handle
@@ -211,8 +214,8 @@ int ac_quat_rows_f32(ac_handle* h, int mode, const float* X, const float* Xdot, 
  * Hout [H][21][21][B]. */
 int ac_step_hess_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit,
                      const float* lambda, long n, float* Hout, void* stream);
-/* Size the second-order workspaces for n units: the MLP path's stage tensors and, when the handle integrates with more
- * than one RK4 sub-step, the composition buffers (hipFree + hipMalloc when one must grow: implicit device synchronisation,
+/* Size the second-order workspaces for n units: the MLP path's stage tensors (and the reverse sweep's scratch) and, when the
+ * handle integrates with more than one RK4 sub-step, the composition buffers (hipFree + hipMalloc when one must grow: implicit device synchronisation,
  * not capturable); a no-op when both are already large enough.  Call again after changing `substeps`. */
 int ac_reserve_hess_workspace(ac_handle* h, long n);
 int ac_shoot_hess_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit,

@@ -12,6 +12,10 @@ cp $G/r3_pmc_counters.json $P/r03_pmc_counters.json
 cp $G/r3_batch_sweep.jsonl $P/r03_batch_sweep.jsonl
 cp $G/r3_bench_modes.jsonl $P/r03_bench_modes.jsonl
 grep -v amdgpu.ids $G/r3_bench_hess.txt > $P/r03_bench_hess.txt
+cp $G/r3_kernel_stats_hess.csv $P/r03_kernel_stats_hess.csv
+cp $G/r3_hess_rev_ab.txt $P/r03_hess_rev_ab.txt
+cp $G/r3_hess_rev_clocks.txt $P/r03_hess_rev_clocks.txt
+grep "stage_tensors\|step_hess" $G/r3_hess_rev_pmc.txt > $P/r03_hess_rev_pmc.txt
 grep -v amdgpu.ids $G/r3_clock_ratio_final.txt > $P/r03_wave_clocks.txt
 cp $G/r3_pair_stub.jsonl $P/r03_pair_stub.jsonl
 cp $G/r3_smi_clocks.txt $P/r03_smi_clocks_power.txt
