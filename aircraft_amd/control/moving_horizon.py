@@ -30,6 +30,39 @@ def _torch():
     return torch
 
 
+class quiet_capture:
+    """torch.cuda.graph(g, stream=...) with Python's cyclic garbage collector run first and paused inside.  A collection
+    that happens to start during the capture may finalise an `Aircraft` of some earlier computation; its close() frees
+    device memory (ac_destroy: hipFree), which is not permitted while a stream of the process is capturing and invalidates
+    the graph ("operation failed due to a previous error during capture").  torch >= 2.9 no longer collects on entry."""
+
+    def __init__(self, graph, stream):
+        self.graph, self.stream, self._ctx, self._was = graph, stream, None, False
+
+    def __enter__(self):
+        import gc
+
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+        self._ctx = _torch().cuda.graph(self.graph, stream=self.stream)
+        try:
+            return self._ctx.__enter__()
+        except BaseException:
+            if self._was:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        import gc
+
+        try:
+            return self._ctx.__exit__(*exc)
+        finally:
+            if self._was:
+                gc.enable()
+
+
 class RecedingHorizon:
     def __init__(self, solver: ILQR, overlap: int = 30, iterations: int = 2, warm_start: str = "shift"):
         """overlap: nodes of each solve that are discarded (mhtt.py:77); iterations: iLQR iterations per solve;
@@ -99,7 +132,7 @@ class RecedingHorizon:
             if s0 is not None:
                 s0.copy_(s0_saved)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
+            with quiet_capture(g, side):
                 self.cycle()
             self.x0.copy_(x0); self.U.copy_(U); self.X.copy_(X)
             if s0 is not None:

@@ -213,13 +213,15 @@ def test_hipgraph_capture_of_the_inner_step(gpu):
     step()
     torch.cuda.synchronize()
     ref = [t.clone() for t in (traj, out[0], out[1], out[2])]
+    from aircraft_amd.control.moving_horizon import quiet_capture
+
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
         step()
         torch.cuda.synchronize()
-        with torch.cuda.graph(g, stream=s):
+        with quiet_capture(g, s):  # (garbage collector paused: a finaliser's hipFree would invalidate the capture)
             step()
     torch.cuda.current_stream().wait_stream(s)
     for t in (traj, out[0], out[1], out[2]):
