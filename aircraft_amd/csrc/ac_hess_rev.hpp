@@ -261,8 +261,188 @@ struct MlpEngineRev : MlpEngine<6, WT, true, true> {
     }
 };
 
-// float4 of scratch per wave: h_1 + the full state of the hidden layers 2 .. nh (slot l - 2 for layer l)
-constexpr long rev_scratch_f32x4(int wt, int nh) { return (long)(1 + 6 * (nh > 1 ? nh - 1 : 0)) * wt * 64; }
+// ---- the reverse sweep in two halves over the outputs (k = 0..2, then 3..5) ------------------------------------------------
+// Same algorithm; the reverse phase holds THREE slabs (96 registers) and 45 sums instead of six and 90, so it fits the
+// vector file without scratch traffic.  Price: the transposed blocks stream twice per stage (the ring is sequenced by hand:
+// acquire_seq), every layer state is read twice and the top one goes through the scratch as well, and the 15 products
+// c s^a s^b of a neuron are formed in both halves.
+template <int WT>
+struct MlpEngineRev3 : MlpEngineRev<WT> {
+    typedef MlpEngineRev<WT> Rev;
+    typedef typename Rev::Base Base;
+    typedef typename Rev::f32x2 f32x2;
+    using Base::a;
+    using Base::g;
+    using Base::lane;
+    AC_DI MlpEngineRev3(const MlpPlan& pl, const float* blob, char* lds_base) : Rev(pl, blob, lds_base) {}
+
+    // The streamed block the ring holds next (whatever block that is: the caller knows the order), and the copy of block `nl`
+    // into the other slot started — MlpEngine::acquire with the successor named instead of read from plan.streamed[].
+    AC_DI const char* acquire_seq(int nl) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* wl = this->lds + this->plan.ring_off[this->ring_pos & 1];
+        lds_dma_copy(this->gblob + this->plan.g_off[nl], this->lds + this->plan.ring_off[(this->ring_pos + 1) & 1], this->plan.bytes[nl],
+                     this->wave, this->nwaves, lane);
+        ++this->ring_pos;
+        return wl;
+    }
+    // a[s] <- B a[s], slabs 0..2 (layer_raw of the six-slab sweep)
+    AC_DI void layer_raw3(const char* wl) {
+        const f32x4* wf = reinterpret_cast<const f32x4*>(wl) + lane;
+        constexpr int C = WT < 4 ? WT : 4;
+        f32x4 wcur[C], wnext[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) wcur[i] = wf[(i * WT + 0) * 64];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            f32x4 o[WT];
+#pragma unroll
+            for (int nc = 0; nc < WT; nc += C) {
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 acc[C];
+#pragma unroll
+                for (int i = 0; i < C; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kt = 0; kt < WT; ++kt) {
+                    const bool last = kt + 1 == WT;
+                    const bool fetch = !last || !(s == 2 && nc + C >= WT);
+#pragma unroll
+                    for (int i = 0; i < C; ++i) acc[i] = mma_16x16x4<true>(wcur[i][0], a[s][kt][0], acc[i]);
+                    if (fetch) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int nnc = last ? (nc + C) % WT : nc, nkt = last ? 0 : kt + 1;
+#pragma unroll
+                        for (int i = 0; i < C; ++i) wnext[i] = wf[((nnc + i) * WT + nkt) * 64];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int r = 1; r < 4; ++r)
+#pragma unroll
+                        for (int i = 0; i < C; ++i) acc[i] = mma_16x16x4<true>(wcur[i][r], a[s][kt][r], acc[i]);
+                    if (fetch) {
+#pragma unroll
+                        for (int i = 0; i < C; ++i) wcur[i] = wnext[i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < C; ++i) o[nc + i] = acc[i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < WT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[s][nt][r] = o[nt][r];
+        }
+    }
+    // a[j] = row k0 + j of the last layer (k0 = 3 half) times rs3[j], from the `wlt` image of last_valu
+    AC_DI void load_top_rows3(const char* wl_last, int half, const float (&rs3)[3]) {
+        const f32x4* wv = reinterpret_cast<const f32x4*>(wl_last + 1024) + g * 6;
+#pragma unroll
+        for (int t = 0; t < WT; ++t) {
+            f32x4 w[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w[i] = wv[t * 24 + i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int ka = j, kb = 3 + j;  // the two candidates: first and second half
+                    const float va = w[2 * (ka >> 1) + (r >> 1)][(ka & 1) + 2 * (r & 1)];
+                    const float vb = w[2 * (kb >> 1) + (r >> 1)][(kb & 1) + 2 * (r & 1)];
+                    a[j][t][r] = (half ? vb : va) * rs3[j];
+                }
+        }
+    }
+    // one neuron: acc[j][q] (pairs over ab = 2q, 2q + 1; entry 15 is padding) += R[j] * c s^a s^b, j = 0..2
+    AC_DI static void contract1_3(float c, const float (&s)[5], const float (&R)[3], f32x2 (&acc)[3][8]) {
+        float u[5], p[16];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) u[i] = c * s[i];
+        int pi = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = i; j < 5; ++j, ++pi) p[pi] = u[i] * s[j];
+        p[15] = 0.f;
+        const f32x2 r01 = {R[0], R[1]}, r2x = {R[2], R[2]};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x2 pp = {p[2 * q], p[2 * q + 1]};
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[0][q]) : "v"(r01), "v"(pp));
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[1][q]) : "v"(r01), "v"(pp));
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[2][q]) : "v"(r2x), "v"(pp));
+        }
+    }
+    // any hidden layer but the first: state from the scratch, R in slabs 0..2; leaves a[j] = R[j] . act'
+    AC_DI void contract3_mid(const f32x4* __restrict__ sl, f32x2 (&acc)[3][8]) {
+        f32x4 cur[6], nxt[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cur[i] = sl[(i * WT + 0) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < WT; ++t) {
+            if (t + 1 < WT) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) nxt[i] = sl[(i * WT + t + 1) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float R[3], s[5];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) R[j] = a[j][t][r];
+                const float h = cur[0][r], sp = fmaf(-h, h, 1.0f);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) s[i] = cur[1 + i][r];
+                contract1_3(Rev::curv_over_slope(h, sp), s, R, acc);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) a[j][t][r] = R[j] * sp;
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) cur[i] = nxt[i];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    AC_DI void contract3_bottom(const f32x4* __restrict__ sl, const char* wl0, f32x2 (&acc)[3][8]) {
+        const f32x4* w0t = reinterpret_cast<const f32x4*>(wl0 + 1024);
+#pragma unroll
+        for (int t = 0; t < WT; ++t) {
+            const f32x4 h4 = sl[t * 64 + lane];
+            f32x4 w[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) w[j] = w0t[j * (WT * 4) + 4 * t + g];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float R[3], s[5];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) R[j] = a[j][t][r];
+                const float h = h4[r], sp = fmaf(-h, h, 1.0f);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) s[i] = w[i][r];
+                contract1_3(-2.0f * h * sp, s, R, acc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // the layer's 48 sums (flat = 16 j + ab) reduce-scattered over the unit's four lanes into 12 running totals per lane
+    AC_DI static void fold3(const f32x2 (&acc)[3][8], float (&tot)[12]) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int f = 4 * q + e;
+                v[e] = acc[f / 16][(f % 16) >> 1][f & 1];
+            }
+            tot[q] += Base::unit_scatter4(v);
+        }
+    }
+};
+
+// float4 of scratch per wave: h_1 + the full state of the hidden layers 2 .. nh + 1 (slot l - 2 for layer l; the six-slab
+// kernel keeps the top one in registers and leaves its slot unused)
+constexpr long rev_scratch_f32x4(int wt, int nh) { return (long)(1 + 6 * nh) * wt * 64; }
 
 // Persistent workgroups (one per CU: the 131 KB weight plan), task = 64 units.  `plan` = plan_rev: entries 0 .. L-1 the net as
 // in plan_sens, L .. L+nh-1 the transposed hidden blocks of the layers nh, nh-1, .., 1 (nh = L - 2 >= 1).
@@ -421,6 +601,174 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors_rev(const DevPar
 #ifdef AC_REV_CLOCKS
     if ((threadIdx.x & 63) == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && threadIdx.x < 128)
         printf("rev clocks block %d wave %d: fwd %llu last %llu top %llu raw %llu mid %llu bottom %llu fold %llu rest %llu\n", (int)blockIdx.x,
+               (int)(threadIdx.x >> 6), clk[0], clk[1], clk[2], clk[3], clk[4], clk[5], clk[6], clk[7]);
+#endif
+}
+
+// The same stage tensors with the reverse sweep in two halves (MlpEngineRev3).  Same arguments, same scratch layout.
+template <int WT>
+__global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors_rev3(const DevParams P, const MlpPlan plan,
+                                                                     const float* __restrict__ blob,
+                                                                     const float* __restrict__ X, const float* __restrict__ U,
+                                                                     float dt, const float* __restrict__ dt_per_unit, long n,
+                                                                     long blk, int L, float* __restrict__ scratch,
+                                                                     float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef MlpEngineRev3<WT> E;
+    E eng(plan, blob, smem);
+    eng.load_weights();  // resident blocks + block 1 in ring slot 0
+    const int nh = L - 2;
+    f32x4* const mine0 = reinterpret_cast<f32x4*>(scratch) +
+                         ((long)blockIdx.x * (kBlock >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) *
+                             rev_scratch_f32x4(WT, nh);
+    const long ntasks = (n + 63) / 64;
+#ifdef AC_REV_CLOCKS
+    unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
+#pragma nounroll
+    for (long task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const WaveUnit w(tid, task, n, blk);
+        float x0[13], u[7];
+        load_rows<13>(X, w.ua, x0);
+        load_rows<7>(U, w.ua, u);
+        const float h = dt_per_unit ? dt_per_unit[w.unit] : dt;
+        float xs[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) xs[i] = x0[i];
+#pragma nounroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4* mine = mine0;
+            asm volatile("" : "+s"(mine));
+            AeroPre<float> ap;
+            aero_pre(P, xs, ap);
+            const float in[5] = {ap.qbar, ap.alpha, ap.beta, u[0], u[1]};
+            float z[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) z[j] = (in[j] - P.mlp_in_mean[j]) / P.mlp_in_std[j];
+            // ---- forward: the state after EVERY hidden layer to the scratch
+            const char* wl0 = eng.Base::acquire(0);
+            eng.first_valu(wl0, z);
+            eng.template store_state<1>(mine);
+#pragma nounroll
+            for (int l = 1; l <= nh; ++l) {
+                const char* wl = eng.acquire_seq(l < nh ? l + 1 : L);
+                eng.template layer<WT, WT, 1>(wl, 1);
+                eng.template store_state<6>(mine + WT * 64 + (long)(l - 1) * 6 * WT * 64);
+            }
+            AC_REV_TICK(0);
+            float y[6];
+            const char* wll = eng.Base::acquire(L - 1);
+            const int act_last = plan.act[L - 1];
+            {
+                float J[6][5];
+                eng.template last_valu<5>(wll, act_last, y, J);
+                if (w.live && w.g == 0) {
+                    float* o = out + w.ua.late().off(kStageFloats) + (long)s * kStageRows * blk;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        o[(long)k * blk] = y[k];
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) o[(long)(6 + k * 5 + i) * blk] = J[k][i];
+                    }
+                }
+            }
+            AC_REV_TICK(1);
+            // ---- reverse sweep, outputs 3 half .. 3 half + 2
+            float tot[2][12];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int q = 0; q < 12; ++q) tot[hf][q] = 0.f;
+#pragma nounroll
+            for (int half = 0; half < 2; ++half) {
+                float rs3[3], y3[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    y3[j] = half ? y[3 + j] : y[j];
+                    rs3[j] = act_last ? fmaf(-y3[j], y3[j], 1.0f) : 1.0f;
+                }
+                eng.load_top_rows3(wll, half, rs3);
+                float th[12];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) th[q] = 0.f;
+                AC_REV_TICK(6);  // (rows of the last layer into the slabs: with the folds)
+                // hidden layers nh + 1 (the top one: R = the rows just loaded) .. 1; ONE instance of the contraction code for all of
+                // them (a separate call for the top layer came out of the register allocator 2.3 times slower than the loop's)
+#pragma nounroll
+                for (int l = nh + 1; l >= 1; --l) {
+                    if (l <= nh) {
+                        const int i = nh - l;  // transposed block L + i; its successor: the next one, or L again / block 1 of the next stage
+                        eng.layer_raw3(eng.acquire_seq(i + 1 < nh ? L + i + 1 : (half == 0 ? L : 1)));
+                    }
+                    AC_REV_TICK(3);
+                    typename E::f32x2 acc[3][8];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc[j][q] = typename E::f32x2{0.f, 0.f};
+                    if (l > 1) {
+                        eng.contract3_mid(mine + WT * 64 + (long)(l - 2) * 6 * WT * 64, acc);
+                    } else {
+                        eng.contract3_bottom(mine, wl0, acc);
+                        if (act_last && w.g == 0) {  // y = tanh(p): + act''(p_k) dp/dz_a dp/dz_b = -2 y_k J_a J_b / act'(p_k), once per unit; J from
+                                                     // the rows lane group 0 of this very wave stored above
+                            const float* o = out + w.ua.late().off(kStageFloats) + (long)s * kStageRows * blk;
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                float Jr[5];
+#pragma unroll
+                                for (int a5 = 0; a5 < 5; ++a5) Jr[a5] = o[(long)(6 + ((half ? 3 : 0) + j) * 5 + a5) * blk];
+                                const float c2 = E::Rev::curv_over_slope(y3[j], rs3[j]);
+                                int pi = 0;
+#pragma unroll
+                                for (int a5 = 0; a5 < 5; ++a5)
+#pragma unroll
+                                    for (int b5 = a5; b5 < 5; ++b5, ++pi) acc[j][pi >> 1][pi & 1] += c2 * Jr[a5] * Jr[b5];
+                            }
+                        }
+                    }
+                    if (l > nh) AC_REV_TICK(2); else if (l > 1) AC_REV_TICK(4); else AC_REV_TICK(5);
+                    E::fold3(acc, th);
+                    AC_REV_TICK(6);
+                }
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {
+                    if (half == 0) tot[0][q] = th[q]; else tot[1][q] = th[q];
+                }
+            }
+            // ---- T: lane group g holds entry 4 q + (0, 2, 1, 3)[g] of each half's 48 (flat = 16 j + ab, ab = 15 padding)
+            if (w.live) {
+                float* o = out + w.ua.late().off(kStageFloats) + (long)s * kStageRows * blk;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) {
+                        const int f = 4 * q + (w.g == 0 ? 0 : w.g == 1 ? 2 : w.g == 2 ? 1 : 3);
+                        const int ab = f & 15, k = 3 * hf + (f >> 4);
+                        if (ab < 15) o[(long)(36 + k * 15 + ab) * blk] = tot[hf][q];
+                    }
+            }
+            if (s < 3) {
+                load_rows<13>(X, w.ua, x0);
+                load_rows<7>(U, w.ua, u);
+                GivenY prov;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) prov.y[k] = y[k];
+                float k1[13];
+                state_derivative<float>(P, prov, xs, u, k1);
+                const float hs = h * ((s == 2) ? 1.0f : 0.5f);
+#pragma unroll
+                for (int i = 0; i < 13; ++i) xs[i] = fmaf(hs, k1[i], x0[i]);
+            }
+            AC_REV_TICK(7);
+        }
+    }
+    eng.drain();
+#ifdef AC_REV_CLOCKS
+    if ((threadIdx.x & 63) == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && threadIdx.x < 128)
+        printf("rev3 clocks block %d wave %d: fwd %llu last %llu top %llu raw %llu mid %llu bottom %llu fold %llu rest %llu\n", (int)blockIdx.x,
                (int)(threadIdx.x >> 6), clk[0], clk[1], clk[2], clk[3], clk[4], clk[5], clk[6], clk[7]);
 #endif
 }

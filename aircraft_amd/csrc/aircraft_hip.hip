@@ -1107,7 +1107,11 @@ static int hess_single(ac_handle* h, const float* X, const float* U, float dt, c
             const size_t need_r = (size_t)grid_r * (kBlock / 64) * (size_t)rev_scratch_f32x4(h->wt, h->rev_layers - 2) * 4;
             if (need_r > h->rev_scratch_floats)
                 return fail(AC_ERR_WORKSPACE, "second-order workspace too small: call ac_reserve_hess_workspace(h, n) first");
+#ifdef AC_HESS_REV6  // (A/B flavour: the six-slab reverse sweep, tools/variant_lib.sh)
             auto kern = k_nn_stage_tensors_rev<8>;
+#else
+            auto kern = k_nn_stage_tensors_rev3<8>;
+#endif
             int rc_ = set_lds_limit(h, kern, h->plan_rev.lds_total);
             if (rc_ != AC_OK) return rc_;
             hipLaunchKernelGGL(kern, grid_r, kBlock, h->plan_rev.lds_total, st, h->dp, h->plan_rev, h->d_blob, X, U, dt, dt_per_unit,
