@@ -18,6 +18,9 @@
 // 12 slab-layer products per hidden layer instead of 29, + the contraction (~1.5 slab-layer products' worth of vector
 // instructions per layer).  tanh on every hidden layer (ac_set_mlp's fold guarantees it); an activation on the LAST layer
 // adds act'(p_k) to R_top and the term act''(p_k) J_a J_b.
+// Two kernels: k_nn_stage_tensors_rev (all six rows in one reverse sweep: 192 slab registers + 90 sums — hipcc's allocator
+// leaves 1 200 B of scratch per lane in it; kept as the A/B flavour -DAC_HESS_REV6) and k_nn_stage_tensors_rev3, the product:
+// the reverse sweep twice with three rows each (96 slab registers + 45 sums: 208 B of scratch), 20.1 -> 17.55 ms per call.
 #pragma once
 #include "ac_hess_nn.hpp"
 

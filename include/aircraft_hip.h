@@ -199,7 +199,7 @@ int ac_quat_rows_f32(ac_handle* h, int mode, const float* X, const float* Xdot, 
  * without effect are zero.  All force models.  The MLP surrogate evaluates its second-derivative tensor with the MFMA
  * engine (hidden width 128 with two or three hidden 128 x 128 products: forward tangents + a reverse sweep through the
  * transposed blocks, csrc/ac_hess_rev.hpp, which also keeps per-wave layer states in a handle-owned scratch of
- * CUs x 4 x (1 + 6 (hidden products - 1)) x 8 KiB; otherwise one slab per derivative, csrc/ac_hess_nn.hpp)
+ * CUs x 4 x (1 + 6 hidden products) x 8 KiB; otherwise one slab per derivative, csrc/ac_hess_nn.hpp)
  * into a handle-owned workspace of n*504 floats: size it once with ac_reserve_hess_workspace(h, n_max) — a
  * host-side call that may allocate — BEFORE the first compute call (and before capturing a hipGraph); the compute calls
  * themselves never allocate, free or synchronise and return AC_ERR_WORKSPACE when the workspace is too small.  The

@@ -9,8 +9,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r3_prof_hess 
 python tools/kernel_trace_stats.py $(ls gpurun_out/r3_prof_hess/*/*_kernel_trace.csv | head -1) --skip 1 > gpurun_out/r3_kernel_stats_hess.csv || true
 cat gpurun_out/r3_kernel_stats_hess.csv
 rm -f gpurun_out/hess_rev_*.npz
-if [ -f $L/libaircraft_hip_norev.so ]; then
-  (AIRCRAFT_HIP_LIB=$L/libaircraft_hip_norev.so python tools/hess_rev_ab.py norev; python tools/hess_rev_ab.py rev) 2>&1 | grep -v amdgpu > gpurun_out/r3_hess_rev_ab.txt || true
+if [ -f $L/libaircraft_hip_norev.so ] && [ -f $L/libaircraft_hip_rev6.so ]; then
+  # norev: one slab per derivative (round 2); rev6: reverse sweep with six slabs; rev: the product (two halves of three slabs)
+  (AIRCRAFT_HIP_LIB=$L/libaircraft_hip_norev.so python tools/hess_rev_ab.py norev; AIRCRAFT_HIP_LIB=$L/libaircraft_hip_rev6.so python tools/hess_rev_ab.py rev6; python tools/hess_rev_ab.py rev) 2>&1 | grep -v amdgpu > gpurun_out/r3_hess_rev_ab.txt || true
   cat gpurun_out/r3_hess_rev_ab.txt
 fi
 if [ -f $L/libaircraft_hip_rev_clk.so ]; then

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Four calls of the second-order blocks of the 4x128 surrogate at B x H = 204 800 — the program to put behind rocprofv3 --kernel-trace --stats
 (round 2: k_nn_stage_tensors<8,true,0> 14.1 ms + <8,true,1> 5.9 ms + k_step_hess<2,2> 6.3 ms per call; round 3:
-k_nn_stage_tensors_rev<8> 13.6 ms + k_step_hess 6.3 ms)."""
+k_nn_stage_tensors_rev3<8> 11.2 ms + k_step_hess 6.3 ms)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

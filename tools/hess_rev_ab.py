@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the width-128 second-order path: run with AIRCRAFT_HIP_LIB unset (reverse sweep) and with the -DAC_NO_HESS_REV
-flavour (tools/variant_lib.sh: UNITS="aircraft_hip" ... norev -DAC_NO_HESS_REV); each run saves its stage tensors and blocks
+flavour (tools/variant_lib.sh: UNITS="aircraft_hip" ... norev -DAC_NO_HESS_REV; rev6 -DAC_HESS_REV6: the six-slab reverse sweep); each run saves its stage tensors and blocks
 for a small batch and times the full-size call.   usage: hess_rev_ab.py <tag> [hidden widths ...]"""
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,8 +40,11 @@ for n in (1000, 204800):
         print(f"{tag}: hidden {hidden}  n = {n}: step_hess {min(t):.2f} ms (min of 5; {', '.join('%.2f' % v for v in t)})", flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 np.savez(os.path.join(ROOT, "gpurun_out", f"hess_rev_{tag}.npz"), **out)
-other = os.path.join(ROOT, "gpurun_out", f"hess_rev_{'norev' if tag == 'rev' else 'rev'}.npz")
-if os.path.exists(other):
+for ref in ("norev", "rev6"):  # compare with whatever flavours ran before in this call
+    other = os.path.join(ROOT, "gpurun_out", f"hess_rev_{ref}.npz")
+    if ref == tag or not os.path.exists(other):
+        continue
+    print(f" {tag} against {ref}:")
     o = np.load(other)
     for k in ("stage", "Hz"):
         a, b = out[k].astype(np.float64), o[k].astype(np.float64)
