@@ -250,7 +250,7 @@ def test_hessian_reads_nothing_it_did_not_write(gpu, hidden):
 
 @pytest.mark.parametrize("model,hidden,substeps,normalise", [("default", None, 3, True), ("poly", None, 10, False),
                                                              ("poly", None, 10, True), ("nn", (64, 64, 64), 4, True),
-                                                             ("nn", None, 10, True)])
+                                                             ("nn", None, 10, True), ("nn", (128, 128, 128), 3, True)])
 def test_hessian_composed_over_substeps(gpu, model, hidden, substeps, normalise):
     """physical_integration_substeps > 1 (the reference's default is 10): the blocks of the sub-steps composed on the
     device — sum_s T_s' H_s T_s with the first-order chain and the pulled-back multipliers — against central differences
