@@ -32,9 +32,9 @@ namespace ac {
 #define AC_REV_TICK(i) do { } while (0)
 #endif
 
-template <int WT>
-struct MlpEngineRev : MlpEngine<6, WT, true, true> {
-    typedef MlpEngine<6, WT, true, true> Base;
+template <int WT, bool MF = true>  // MF = false: the cross-lane validation form of the 16x16x4 product ("MFMA off")
+struct MlpEngineRev : MlpEngine<6, WT, MF, true> {
+    typedef MlpEngine<6, WT, MF, true> Base;
     using Base::a;
     using Base::g;
     using Base::lane;
@@ -65,7 +65,7 @@ struct MlpEngineRev : MlpEngine<6, WT, true, true> {
                     const bool last = kt + 1 == WT;
                     const bool fetch = !last || !(s == 5 && nc + C >= WT);
 #pragma unroll
-                    for (int i = 0; i < C; ++i) acc[i] = mma_16x16x4<true>(wcur[i][0], a[s][kt][0], acc[i]);
+                    for (int i = 0; i < C; ++i) acc[i] = mma_16x16x4<MF>(wcur[i][0], a[s][kt][0], acc[i]);
                     if (fetch) {
                         __builtin_amdgcn_sched_barrier(0);
                         const int nnc = last ? (nc + C) % WT : nc, nkt = last ? 0 : kt + 1;
@@ -76,7 +76,7 @@ struct MlpEngineRev : MlpEngine<6, WT, true, true> {
 #pragma unroll
                     for (int r = 1; r < 4; ++r)
 #pragma unroll
-                        for (int i = 0; i < C; ++i) acc[i] = mma_16x16x4<true>(wcur[i][r], a[s][kt][r], acc[i]);
+                        for (int i = 0; i < C; ++i) acc[i] = mma_16x16x4<MF>(wcur[i][r], a[s][kt][r], acc[i]);
                     if (fetch) {
 #pragma unroll
                         for (int i = 0; i < C; ++i) wcur[i] = wnext[i];
@@ -269,9 +269,9 @@ struct MlpEngineRev : MlpEngine<6, WT, true, true> {
 // vector file without scratch traffic.  Price: the transposed blocks stream twice per stage (the ring is sequenced by hand:
 // acquire_seq), every layer state is read twice and the top one goes through the scratch as well, and the 15 products
 // c s^a s^b of a neuron are formed in both halves.
-template <int WT>
-struct MlpEngineRev3 : MlpEngineRev<WT> {
-    typedef MlpEngineRev<WT> Rev;
+template <int WT, bool MF = true>
+struct MlpEngineRev3 : MlpEngineRev<WT, MF> {
+    typedef MlpEngineRev<WT, MF> Rev;
     typedef typename Rev::Base Base;
     typedef typename Rev::f32x2 f32x2;
     using Base::a;
@@ -311,7 +311,7 @@ struct MlpEngineRev3 : MlpEngineRev<WT> {
                     const bool last = kt + 1 == WT;
                     const bool fetch = !last || !(s == 2 && nc + C >= WT);
 #pragma unroll
-                    for (int i = 0; i < C; ++i) acc[i] = mma_16x16x4<true>(wcur[i][0], a[s][kt][0], acc[i]);
+                    for (int i = 0; i < C; ++i) acc[i] = mma_16x16x4<MF>(wcur[i][0], a[s][kt][0], acc[i]);
                     if (fetch) {
                         __builtin_amdgcn_sched_barrier(0);
                         const int nnc = last ? (nc + C) % WT : nc, nkt = last ? 0 : kt + 1;
@@ -322,7 +322,7 @@ struct MlpEngineRev3 : MlpEngineRev<WT> {
 #pragma unroll
                     for (int r = 1; r < 4; ++r)
 #pragma unroll
-                        for (int i = 0; i < C; ++i) acc[i] = mma_16x16x4<true>(wcur[i][r], a[s][kt][r], acc[i]);
+                        for (int i = 0; i < C; ++i) acc[i] = mma_16x16x4<MF>(wcur[i][r], a[s][kt][r], acc[i]);
                     if (fetch) {
 #pragma unroll
                         for (int i = 0; i < C; ++i) wcur[i] = wnext[i];
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors_rev(const DevPar
 }
 
 // The same stage tensors with the reverse sweep in two halves (MlpEngineRev3).  Same arguments, same scratch layout.
-template <int WT>
+template <int WT, bool MF>
 __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors_rev3(const DevParams P, const MlpPlan plan,
                                                                      const float* __restrict__ blob,
                                                                      const float* __restrict__ X, const float* __restrict__ U,
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors_rev3(const DevPa
                                                                      long blk, int L, float* __restrict__ scratch,
                                                                      float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef MlpEngineRev3<WT> E;
+    typedef MlpEngineRev3<WT, MF> E;
     E eng(plan, blob, smem);
     eng.load_weights();  // resident blocks + block 1 in ring slot 0
     const int nh = L - 2;

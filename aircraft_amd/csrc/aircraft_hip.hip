@@ -379,7 +379,7 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
     // Width 128 on the matrix cores with one to three hidden products: the transposed hidden blocks of the reverse sweep
     // (k_nn_stage_tensors_rev), top hidden layer first, behind the net's own blocks.
     const int n_hid = n_layers - 2;
-    const bool want_rev = use_mfma && wt == 8 && n_hid >= 1 && n_layers + n_hid <= AC_MAX_LAYERS;
+    const bool want_rev = wt == 8 && n_hid >= 1 && n_layers + n_hid <= AC_MAX_LAYERS;  // (both flavours of the matrix product)
     size_t rev_off[AC_MAX_LAYERS] = {0};
     const size_t rev_block_floats = (size_t)wt * wt * 256 + 256;  // fragments + a (zero) bias piece: the hidden blocks' size class
     if (want_rev)
@@ -1101,21 +1101,27 @@ static int hess_single(ac_handle* h, const float* X, const float* U, float dt, c
         const int grid_t = (int)((n + 63) / 64);
         bool launched = false;
 #ifndef AC_NO_HESS_REV
-        if (h->has_rev && h->use_mfma && h->wt == 8) {
+        if (h->has_rev && h->wt == 8) {
             // width 128: forward tangents + reverse sweep (12 slab-layer products per hidden layer instead of 29), persistent grid
             const int grid_r = rev_grid(h, n);
             const size_t need_r = (size_t)grid_r * (kBlock / 64) * (size_t)rev_scratch_f32x4(h->wt, h->rev_layers - 2) * 4;
             if (need_r > h->rev_scratch_floats)
                 return fail(AC_ERR_WORKSPACE, "second-order workspace too small: call ac_reserve_hess_workspace(h, n) first");
+#define AC_REV_LAUNCH(KERN_)                                                                                        \
+            {                                                                                                       \
+                auto kern = KERN_;                                                                                  \
+                int rc_ = set_lds_limit(h, kern, h->plan_rev.lds_total);                                            \
+                if (rc_ != AC_OK) return rc_;                                                                       \
+                hipLaunchKernelGGL(kern, grid_r, kBlock, h->plan_rev.lds_total, st, h->dp, h->plan_rev, h->d_blob, X, U, dt,    \
+                                   dt_per_unit, n, blk, h->rev_layers, h->d_rev_scratch, h->d_hess_ws);            \
+            }
+            if (!h->use_mfma) AC_REV_LAUNCH((k_nn_stage_tensors_rev3<8, false>))  // the cross-lane validation form of the product
 #ifdef AC_HESS_REV6  // (A/B flavour: the six-slab reverse sweep, tools/variant_lib.sh)
-            auto kern = k_nn_stage_tensors_rev<8>;
+            else AC_REV_LAUNCH(k_nn_stage_tensors_rev<8>)
 #else
-            auto kern = k_nn_stage_tensors_rev3<8>;
+            else AC_REV_LAUNCH((k_nn_stage_tensors_rev3<8, true>))
 #endif
-            int rc_ = set_lds_limit(h, kern, h->plan_rev.lds_total);
-            if (rc_ != AC_OK) return rc_;
-            hipLaunchKernelGGL(kern, grid_r, kBlock, h->plan_rev.lds_total, st, h->dp, h->plan_rev, h->d_blob, X, U, dt, dt_per_unit,
-                               n, blk, h->rev_layers, h->d_rev_scratch, h->d_hess_ws);
+#undef AC_REV_LAUNCH
             note_launch(h, "k_nn_stage_tensors_rev", grid_r, kBlock, h->plan_rev.lds_total);
             launched = true;
         } else {

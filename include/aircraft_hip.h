@@ -208,8 +208,8 @@ int ac_quat_rows_f32(ac_handle* h, int mode, const float* X, const float* Xdot, 
  * per-sub-step blocks: d2/dz2 = sum_s T_s' H_s T_s with T_s = d(x_{s-1}, u, dt/ns)/dz carried by the first-order chain and the
  * multipliers pulled back through the later sub-steps (mu_{s-1} = A_s' mu_s); it needs (559 ns + 481) n floats more of the
  * same reserved workspace, sized for the handle's sub-step count at the time of ac_reserve_hess_workspace.
- * AC_ERR_UNSUPPORTED for an MLP wider than 64 with use_mfma = 0 (the cross-lane validation flavour has no second-order
- * instance at that width).  Hout is zero-filled by the call (hipMemsetAsync on `stream`) before the active block is
+ * AC_ERR_UNSUPPORTED for an MLP wider than 64 with use_mfma = 0 unless it has two or three hidden 128 x 128 products (the
+ * reverse-sweep kernel has a cross-lane flavour, the slab-per-derivative kernel at that width has not).  Hout is zero-filled by the call (hipMemsetAsync on `stream`) before the active block is
  * written.  ac_shoot_hess_f32 reads rollout-shaped X [H(+1)][13][B], U [H][7][B], lambda [H][13][B] in place and writes
  * Hout [H][21][21][B]. */
 int ac_step_hess_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit,

@@ -46,7 +46,7 @@ def test_hessian_matches_finite_differences_of_exact_jacobians(gpu, model, norma
 
 
 @pytest.mark.parametrize("hidden,normalise,use_mfma", [((64, 64, 64), True, True), (None, False, True), ((128, 128, 128, 128), True, True),
-                                                       ((32, 32), True, False)])
+                                                       ((32, 32), True, False), ((128, 100, 128), True, False)])
 def test_hessian_mlp_surrogate(gpu, hidden, normalise, use_mfma):
     """MLP surrogate: stage tensors (y, J, d2y/dz dz) from the MFMA engine's second-order mode, then the same
     second-order forward-mode kernel.  hidden=None is the reference's own network (Linear-tanh-Linear)."""
@@ -150,8 +150,9 @@ def test_hessian_workspace_must_be_reserved_through_the_abi(gpu):
 
 
 def test_wide_valu_flavour_is_refused(gpu):
-    """Second-order blocks at width > 64 exist on the MFMA path only (include/aircraft_hip.h): the call must fail loudly,
-    not fall back."""
+    """Second-order blocks at width > 64 with use_mfma = 0 exist for nets with two or three hidden 128 x 128 products only
+    (the reverse-sweep kernel's cross-lane flavour, include/aircraft_hip.h; test_hessian_mlp_surrogate covers one): a net with
+    ONE such product has no instance, and the call must fail loudly, not fall back."""
     import torch
     from aircraft_amd import AircraftHipError
     from tests.helpers import make_aircraft
