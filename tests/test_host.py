@@ -282,3 +282,37 @@ def test_bench_self_launch_plan_and_cpu_refusal():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and not r.stdout.strip()
     assert "starting 2 rank processes" in r.stderr
+
+
+def test_bench_in_run_parity_gate_catches_one_bad_unit():
+    """bench.py's parity_in_run (the figure the driver's bench line carries, exit code 5 when it fails): exact copies pass, ONE
+    unit off by 3e-5 in one entry of A fails, a NaN fails, and only the first `n` units (the cpu_baseline sample) are read."""
+    import importlib.util
+    import os
+
+    import torch
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rng = np.random.default_rng(9)
+    H, B, n = 3, 5, 11  # the sample covers the first 11 of 15 units (node-major)
+    F = rng.normal(size=(H, 13, B)); A = rng.normal(size=(H, 13, 13, B)); Bm = rng.normal(size=(H, 13, 7, B))
+    kept = {"n": n, "Xn": F.transpose(1, 0, 2).reshape(13, H * B)[:, :n].copy(),
+            "A": A.transpose(1, 2, 0, 3).reshape(13, 13, H * B)[:, :, :n].copy(),
+            "B": Bm.transpose(1, 2, 0, 3).reshape(13, 7, H * B)[:, :, :n].copy()}
+    t = lambda a: torch.from_numpy(a.copy())  # noqa: E731
+    ok = bench.parity_in_run(kept, t(F), t(A), t(Bm))
+    assert ok["ok"] and ok["units"] == n and ok["state_block_rel_max"] == 0 and ok["A_unit_rel_max"] == 0
+    bad = A.copy()
+    k, b = 2, 0  # flat unit 2 * 5 + 0 = 10: the last one inside the sample
+    bad[k, 4, 7, b] += 3e-5 * np.abs(A[k, :, :, b]).max()
+    r = bench.parity_in_run(kept, t(F), t(bad), t(Bm))
+    assert not r["ok"] and 2e-5 < r["A_unit_rel_max"] < 4e-5 and r["B_unit_rel_max"] == 0
+    outside = A.copy(); outside[2, 4, 7, 1] += 1.0  # flat unit 11: outside the sample, not read
+    assert bench.parity_in_run(kept, t(F), t(outside), t(Bm))["ok"]
+    nan = F.copy(); nan[0, 3, 2] = np.nan
+    assert not bench.parity_in_run(kept, t(nan), t(A), t(Bm))["ok"]
+    small = F.copy(); small[1, 12, 3] += 5e-6  # omega block: floor 0.1 rad/s -> 5e-5 relative to the floor at most
+    r = bench.parity_in_run(kept, t(small), t(A), t(Bm))
+    assert r["state_block_rel_max"] > 0 and (r["ok"] == (r["state_block_rel_max"] <= 1e-5))
