@@ -316,3 +316,46 @@ def test_bench_in_run_parity_gate_catches_one_bad_unit():
     small = F.copy(); small[1, 12, 3] += 5e-6  # omega block: floor 0.1 rad/s -> 5e-5 relative to the floor at most
     r = bench.parity_in_run(kept, t(small), t(A), t(Bm))
     assert r["state_block_rel_max"] > 0 and (r["ok"] == (r["state_block_rel_max"] <= 1e-5))
+
+
+def test_quiet_capture_pauses_the_garbage_collector_and_restores_it(monkeypatch):
+    """control.moving_horizon.quiet_capture: collector run before, disabled inside, restored after — also when the body or the
+    capture itself raises (a finaliser's hipFree during a capture invalidates the graph; DESIGN §5 / INTEGRATION)."""
+    import gc
+    import types
+
+    from aircraft_amd.control import moving_horizon as mh
+
+    events = []
+
+    class FakeGraphCtx:
+        def __init__(self, graph, stream=None):
+            events.append(("ctx", graph, stream))
+
+        def __enter__(self):
+            events.append(("enter", gc.isenabled()))
+            return self
+
+        def __exit__(self, *exc):
+            events.append(("exit", gc.isenabled(), exc[0]))
+            return False
+
+    fake_torch = types.SimpleNamespace(cuda=types.SimpleNamespace(graph=FakeGraphCtx))
+    monkeypatch.setattr(mh, "_torch", lambda: fake_torch)
+    collected = []
+    monkeypatch.setattr(gc, "collect", lambda *a: collected.append(True) or 0)
+    assert gc.isenabled()
+    with mh.quiet_capture("g", "s"):
+        assert not gc.isenabled()
+    assert gc.isenabled() and collected and events[0] == ("ctx", "g", "s") and events[1] == ("enter", False)
+    with pytest.raises(RuntimeError):
+        with mh.quiet_capture("g", "s"):
+            raise RuntimeError("body failed")
+    assert gc.isenabled() and events[-1][2] is RuntimeError
+    gc.disable()  # a caller that runs with the collector off stays off
+    try:
+        with mh.quiet_capture("g", "s"):
+            pass
+        assert not gc.isenabled()
+    finally:
+        gc.enable()
