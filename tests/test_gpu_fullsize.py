@@ -48,6 +48,39 @@ def test_cfg3_oracle_spot_check(cfg3):
         assert e.max() < 1e-5 and eb.max() < 1e-4, (key, float(e.max()), float(eb.max()))
 
 
+def test_cfg3_second_order_blocks_at_full_size(cfg3):
+    """The nlp_hess_l blocks of all 204 800 units in one call (ac_shoot_hess_f32: 3 200 tasks on a persistent grid of one
+    workgroup per CU — every workgroup runs 12-13 tasks through its scratch slots and the hand-sequenced weight ring): 48 units
+    spread over the first, middle and last tasks against central differences of the oracle's exact float64 Jacobians, and the
+    same units evaluated on their own (one task per workgroup) bit for bit."""
+    import torch
+
+    from tests.helpers import oracle_step_hessian
+
+    ac, ms, X, U = cfg3["ac"], cfg3["ms"], cfg3["X"], cfg3["U"]
+    H, B = 50, 4096
+    rng = np.random.default_rng(4)
+    lam_h = f32_exact(rng.normal(size=(H, 13, B)))
+    Lam = torch.from_numpy(np.ascontiguousarray(lam_h, dtype=np.float32)).to(X.device)
+    Hz = ms.hessian(X, U, Lam)
+    torch.cuda.synchronize()
+    assert Hz.shape == (H, 21, 21, B) and bool(torch.isfinite(Hz).all())
+    # sampled units: flat unit u = k * B + b (node-major); tasks are 64 consecutive units
+    flat = np.concatenate([np.arange(0, 16), 64 * 1599 + np.arange(20, 36), H * B - 16 + np.arange(0, 16)])
+    k, b = flat // B, flat % B
+    Xs = np.ascontiguousarray(cfg3["Xh"][k, :, b].T); Us = np.ascontiguousarray(cfg3["Uh"][k, :, b].T)
+    ls = np.ascontiguousarray(lam_h[k, :, b].T)
+    got = Hz.cpu().numpy()[k, :, :, b].transpose(1, 2, 0).astype(np.float64)
+    want = oracle_step_hessian(make_oracle(ac), Xs, Us, 0.01, ls)
+    num = np.sqrt(((got - want) ** 2).sum(axis=(0, 1))); den = np.sqrt((want ** 2).sum(axis=(0, 1)))
+    rel = float((num / np.maximum(den, 1e-30)).max())
+    parity_report("cfg3_hess_full_size", units=len(flat), rel_block_max=rel)
+    assert rel < 5e-4
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(X.device)  # noqa: E731
+    alone = ac.step_hess(dev(Xs), dev(Us), 0.01, dev(ls))
+    assert torch.equal(alone, torch.from_numpy(np.ascontiguousarray(Hz.cpu().numpy()[k, :, :, b].transpose(1, 2, 0))).to(X.device))
+
+
 def test_cfg3_deterministic_and_shard_invariant(cfg3):
     """Same inputs -> same bits; and a unit's result does not depend on which batch it is evaluated in (the
     multi-GPU sharding relies on it): the full batch equals its two halves evaluated separately."""
