@@ -254,10 +254,13 @@ AC_DI void sens_update(const DevParams& P, Coeffs& coeffs, int g, int col, const
     if (P.p.normalise) normalise_q(x);
 }
 
-// Directions per lane for the analytic models (measured on MI355X, B x H = 204 800): the cubic-polynomial model spills
-// 1 KB/lane with four directions per lane and runs 1.9x faster with two (eight lanes per unit); the cheap default and
-// linear models prefer four (less redundant primal work).
-template <int MODEL> struct AnalyticSensN { static constexpr int value = (MODEL == AC_MODEL_POLY) ? 2 : 4; };
+// Directions per lane for the analytic models: four (four lanes per unit, 16 units per wave).  The kernels are bound by
+// vector-ALU issue (profiles/r04_analytic_pmc_before.json: 79 % of wave cycles in VALU at one wave per SIMD, HBM writes
+// 1.00x the algorithmic bytes), the primal is recomputed by every lane of a unit, so fewer lanes per unit is less work;
+// the structured tangents (ac_dynamics.hpp) keep four directions within 256 registers = two waves per SIMD, which is
+// what lets the SIMD issue a vector instruction every ~2 cycles instead of every 4.
+template <int MODEL> struct AnalyticSensN { static constexpr int value = 4; };
+constexpr int kSensWavesPerSimd = 2;
 // ---- x_dot = f(x, u) with its Jacobians (the implicit defect row and the Baumgarte row differentiate f, not the step:
 // control/base.py:282-304; the LQR wrapper: dynamics/base.py:51-52) -------------------------------------------------
 // One evaluation of f seeded like the first RK4 stage: k[i].d[j] = df_i / d(direction N g + j).
@@ -285,7 +288,7 @@ AC_DI void deriv_store(int g, const UnitAddr& ua, const Dual<N> k[13], float* __
 }
 
 template <int MODEL>
-__global__ __launch_bounds__(kBlock) void k_deriv_sens(const DevParams P, const float* __restrict__ X,
+__global__ __launch_bounds__(kBlock, kSensWavesPerSimd) void k_deriv_sens(const DevParams P, const float* __restrict__ X,
                                                        const float* __restrict__ U, long n, long blk,
                                                        float* __restrict__ Xdot, float* __restrict__ Fx,
                                                        float* __restrict__ Fu) {
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(kBlock) void k_quat_rows(const float* __restrict__ 
 }
 
 template <int MODEL>
-__global__ __launch_bounds__(kBlock) void k_step_sens(const DevParams P, const float* __restrict__ X,
+__global__ __launch_bounds__(kBlock, kSensWavesPerSimd) void k_step_sens(const DevParams P, const float* __restrict__ X,
                                                       const float* __restrict__ U, float dt,
                                                       const float* __restrict__ dt_per_unit, long n, long blk,
                                                       float* __restrict__ Xn, float* __restrict__ A,

@@ -6,7 +6,19 @@
 // Tangent directions are independent given the primal, so a unit's 15 non-trivial directions
 // (v, q, omega, 4 active controls, dt) are spread over 4 lanes x Dual<4>.
 #pragma once
+// -DAC_HOST_CHECK (tests/host_dyn, g++): the arithmetic headers (this one and ac_dynamics.hpp) compile as plain host C++
+// so that the CPU test suite can run the kernels' own math against the float64 oracle without a GPU.  Never defined in
+// the product build.
+#ifdef AC_HOST_CHECK
+#include <cmath>
+#define AC_DI inline
+#define AC_OPAQUE_V(x) ((void)0)
+#else
 #include <hip/hip_runtime.h>
+#define AC_DI __device__ __forceinline__
+// a copy of a per-lane value the optimiser cannot see through (keeps rebuilt 0/1 seed patterns out of long-lived registers)
+#define AC_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#endif
 
 namespace ac {
 
@@ -14,14 +26,12 @@ template <int N>
 struct Dual {
     float v;
     float d[N];
-    __device__ __forceinline__ Dual() {}
-    __device__ __forceinline__ Dual(float x) : v(x) {  // NOLINT (implicit on purpose)
+    AC_DI Dual() {}
+    AC_DI Dual(float x) : v(x) {  // NOLINT (implicit on purpose)
 #pragma unroll
         for (int i = 0; i < N; ++i) d[i] = 0.f;
     }
 };
-
-#define AC_DI __device__ __forceinline__
 
 // ---- in-kernel phase stamps: DIAGNOSTIC build flavor only (-DAC_STAMPS; aircraft_amd/build.py --diag) -----------
 // In the product build AC_MARK() expands to nothing.  In the diagnostic flavor every wave accumulates the shader-clock
@@ -55,9 +65,9 @@ struct Stamper {
 #define AC_MARK(st, id) (st).mark(id)
 #else
 struct Stamper {
-    __device__ __forceinline__ void start() {}
-    __device__ __forceinline__ void mark(int) {}
-    __device__ __forceinline__ void flush(unsigned long long*) {}
+    AC_DI void start() {}
+    AC_DI void mark(int) {}
+    AC_DI void flush(unsigned long long*) {}
 };
 #define AC_MARK(st, id) ((void)0)
 #endif
@@ -81,8 +91,8 @@ struct WaveClock {
         }
     }
 #else
-    __device__ __forceinline__ void start() {}
-    __device__ __forceinline__ void stop(unsigned long long*) {}
+    AC_DI void start() {}
+    AC_DI void stop(unsigned long long*) {}
 #endif
 };
 
@@ -108,6 +118,19 @@ template <int N> AC_DI Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) {
     Dual<N> r; r.v = a.v * b.v;
 #pragma unroll
     for (int i = 0; i < N; ++i) r.d[i] = fmaf(a.d[i], b.v, a.v * b.d[i]);
+    return r;
+}
+// fused forms of the RK4 combinations (one FMA per tangent where the operator forms take a multiply and an add)
+template <int N> AC_DI Dual<N> dual_axpy(float a, const Dual<N>& x, const Dual<N>& y) {  // a x + y
+    Dual<N> r; r.v = fmaf(a, x.v, y.v);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = fmaf(a, x.d[i], y.d[i]);
+    return r;
+}
+template <int N> AC_DI Dual<N> dual_mul_add(const Dual<N>& a, const Dual<N>& x, const Dual<N>& y) {  // a x + y
+    Dual<N> r; r.v = fmaf(a.v, x.v, y.v);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = fmaf(a.v, x.d[i], fmaf(a.d[i], x.v, y.d[i]));
     return r;
 }
 template <int N> AC_DI Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) {

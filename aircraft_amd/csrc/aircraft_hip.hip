@@ -293,6 +293,7 @@ int ac_set_poly(ac_handle* h, const float* coef, const float* intercept) {
     if (!h || !coef || !intercept) return AC_ERR_BAD_ARG;
     memcpy(h->dp.poly_coef, coef, sizeof(float) * 6 * 34);
     memcpy(h->dp.poly_intercept, intercept, sizeof(float) * 6);
+    poly_gradient_tables(h->dp.poly_coef, h->dp.poly_grad);
     h->has_poly = true;
     return AC_OK;
 }

@@ -1,0 +1,80 @@
+"""The kernels' own arithmetic (aircraft_amd/csrc/ac_math.hpp + ac_dynamics.hpp) compiled for the host with g++
+(tests/host_dyn/dyn_host.cpp, -DAC_HOST_CHECK) and checked against the float64 oracle: the fp32 forward-mode tangents of
+the fused RK4 step and of f, lane group by lane group exactly as the sensitivity kernels split them, for every analytic
+model and every directions-per-lane count the kernels instantiate.  No GPU: this is what lets a change to the device
+math be validated in the CPU suite before it ever runs on the card.  (The GPU parity tests remain the parity tests.)"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.helpers import (block_rel_err, f32_exact, make_aircraft, make_oracle, synthetic_units, unit_max_rel,
+                           unit_rowblock_rel)
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_dyn")
+SO = os.path.join(HERE, "libdyn_host.so")
+CSRC = os.path.join(os.path.dirname(HERE), "..", "aircraft_amd", "csrc")
+
+
+def _lib():
+    src = os.path.join(HERE, "dyn_host.cpp")
+    deps = [src] + [os.path.join(CSRC, f) for f in ("ac_math.hpp", "ac_dynamics.hpp")]
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        # -ffp-contract=off: the tolerance below then holds for the least favourable (unfused) rounding
+        subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", SO, src], check=True)
+    L = C.CDLL(SO)
+    fp = C.POINTER(C.c_float)
+    L.host_dyn_sens.restype = C.c_int
+    L.host_dyn_sens.argtypes = [C.c_void_p, fp, fp, fp, C.c_int, C.c_int, fp, fp, C.c_float, C.c_long, fp, fp, fp, fp]
+    return L
+
+
+def _run(ac, what, N, X, U, dt):
+    L = _lib()
+    fp = C.POINTER(C.c_float)
+    n = X.shape[1]
+    p = ac._param_struct()
+    d = ac.coefficient_model.oracle_data() or {}
+    keep = [np.ascontiguousarray(d[k], dtype=np.float32) if k in d else None for k in ("W", "coef", "intercept")]
+    ptr = [a.ctypes.data_as(fp) if a is not None else None for a in keep]
+    Xf, Uf = np.ascontiguousarray(X, dtype=np.float32), np.ascontiguousarray(U, dtype=np.float32)
+    Xn, A, B, c = (np.zeros(s, dtype=np.float32) for s in ((13, n), (13, 13, n), (13, 7, n), (13, n)))
+    rc = L.host_dyn_sens(C.byref(p), ptr[0], ptr[1], ptr[2], what, N, Xf.ctypes.data_as(fp), Uf.ctypes.data_as(fp), dt, n,
+                         Xn.ctypes.data_as(fp), A.ctypes.data_as(fp), B.ctypes.data_as(fp), c.ctypes.data_as(fp))
+    assert rc == 0, rc
+    return Xn, A, B, c
+
+
+def _units(n, seed):
+    X, U = synthetic_units(n, seed=seed, flaps=True)
+    return f32_exact(X), f32_exact(U)
+
+
+@pytest.mark.parametrize("N", [2, 4, 8])
+@pytest.mark.parametrize("normalise", [True, False])
+@pytest.mark.parametrize("model", ["default", "linear", "poly"])
+def test_device_math_step_sens_on_host(model, normalise, N):
+    ac = make_aircraft(model, normalise=normalise, stall_scaling=(model == "default" and not normalise))
+    X, U = _units(300, seed=21)
+    Xn, A, B, c = _run(ac, 0, N, X, U, 0.01)
+    Xr, Ar, Br, cr = make_oracle(ac).step_sens(X, U, 0.01)
+    assert block_rel_err(Xn, Xr) < 1e-5
+    for got, want in ((A, Ar), (B, Br), (c, cr)):
+        assert unit_max_rel(got, want).max() < 1e-5
+        assert unit_rowblock_rel(got, want).max() < 5e-5
+    assert np.array_equal(A[:, :3, :], np.broadcast_to(np.eye(13, dtype=np.float32)[:, :3, None], A[:, :3, :].shape))
+    assert not B[:, 3:6, :].any()
+
+
+@pytest.mark.parametrize("N", [2, 4])
+@pytest.mark.parametrize("model", ["default", "linear", "poly"])
+def test_device_math_derivative_sens_on_host(model, N):
+    ac = make_aircraft(model, stall_scaling=(model == "linear"))
+    X, U = _units(300, seed=22)
+    Xd, Fx, Fu, _ = _run(ac, 1, N, X, U, 0.0)
+    Xr, Fxr, Fur = make_oracle(ac).state_derivative_sens(X, U)
+    assert unit_max_rel(Xd, Xr).max() < 1e-5
+    assert unit_max_rel(Fx, Fxr).max() < 1e-5
+    assert unit_max_rel(Fu, Fur).max() < 1e-5
