@@ -20,12 +20,19 @@ namespace ac {
 struct DevParams {
     ac_params p;
     float linear_W[36];
-    float poly_coef[6 * 34];
-    float poly_intercept[6];
-    // d(fit k)/d(f_v) as a quadratic in f: [k][v][15] over the basis 1, f_0..f_3, f_a f_b (a <= b, sklearn order), derived
-    // from poly_coef on the host (poly_gradient_tables): the sensitivity kernels evaluate value and gradient of the fits on
-    // the primal and chain the tangents through the gradient instead of pushing duals through 34 monomials
-    float poly_grad[6 * 4 * 15];
+    // Tables of the cubic fits in DEVICE memory (the handle's; host memory in the host build of these headers), in rows of
+    // 16 floats = one s_load_dwordx16 each (PolyTab below):
+    //   rows  3 k .. 3 k + 2     fit k: intercept, coef[34], padding
+    //   rows 18 + 4 k + v        d(fit k)/d(f_v) as a quadratic in f over the basis 1, f_0..f_3, f_a f_b (a <= b, sklearn
+    //                            order) — derived from coef on the host (poly_gradient_tables): the sensitivity kernels
+    //                            evaluate value and gradient of the fits on the primal and chain the tangents through the
+    //                            gradient instead of pushing duals through 34 monomials
+    // NOT kernel-argument arrays: 570 wave-uniform floats read inside the RK4 stage loop are loop-invariant scalar
+    // loads, which hipcc hoists out of the loop into ~570 scalar registers it does not have and spills lane by lane
+    // into vector registers (v_writelane / v_readlane: a third of the vector instructions of the round-3 poly kernels).
+    // PolyTab reads them behind a pointer the optimiser cannot see through, taken anew wherever a fit is evaluated, and
+    // the evaluations stream the rows two at a time (the next pair in flight while the current one is consumed).
+    const float* poly_tab;
     float mlp_in_mean[5], mlp_in_std[5], mlp_out_mean[6], mlp_out_std[6];
     // mlp_out_std[k] / mlp_in_std[j], rounded once on the host (IEEE single division, what the device computes too): the
     // chain rule dC_k = sum_j J[k][j] * jscale[k][j] * d(in_j) reads them as scalar operands instead of holding thirty
@@ -34,6 +41,64 @@ struct DevParams {
 };
 
 constexpr float kDeg = 0.017453292519943295f;  // pi/180
+
+constexpr int kPolyTabRows = 42, kPolyTabFloats = kPolyTabRows * 16;
+struct Row16 { float c[16]; };
+struct PolyTab {
+    const AC_CONSTANT float* t;
+    AC_DI explicit PolyTab(const DevParams& P) {
+        const float* p = P.poly_tab;
+        AC_OPAQUE_S(p);
+        t = (const AC_CONSTANT float*)__builtin_assume_aligned((const AC_CONSTANT float*)p, 64);
+    }
+    AC_DI float coef(int k, int q) const { return t[k * 48 + 1 + q]; }
+    AC_DI float intercept(int k) const { return t[k * 48]; }
+    AC_DI float grad(int k, int v, int q) const { return t[(18 + k * 4 + v) * 16 + q]; }
+    // Request row r: ONE s_load_dwordx16, as a volatile asm statement — plain loads from the constant address space are
+    // speculatable, and hipcc gathers every row of a stage into the first basic block that dominates their uses (ahead of
+    // the branches inside atan2f / asinf), 40 rows = 640 scalar registers at once.  arrive() is the matching wait; it takes
+    // the row as an in/out operand so that every use is ordered behind it.
+    AC_DI Row16 row(int r) const {
+        Row16 o;
+#ifdef AC_HOST_CHECK
+        for (int i = 0; i < 16; ++i) o.c[i] = t[r * 16 + i];
+#else
+        typedef float v16f __attribute__((ext_vector_type(16)));
+        v16f v;
+        const int off = r * 64;
+        asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(t), "s"(off));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o.c[i] = v[i];
+#endif
+        return o;
+    }
+    static AC_DI void arrive(Row16& a, Row16& b) {
+#ifndef AC_HOST_CHECK
+        typedef float v16f __attribute__((ext_vector_type(16)));
+        v16f va, vb;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { va[i] = a.c[i]; vb[i] = b.c[i]; }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(va), "+s"(vb));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a.c[i] = va[i]; b.c[i] = vb[i]; }
+#else
+        (void)a; (void)b;
+#endif
+    }
+    static constexpr int value_row(int k, int part) { return 3 * k + part; }
+    static constexpr int grad_row(int k, int v) { return 18 + 4 * k + v; }
+};
+// host side of the layout
+inline void poly_pack_tables(const float* coef /*[6][34]*/, const float* intercept /*[6]*/, const float* grad /*[6][4][15]*/,
+                             float* tab /*[kPolyTabFloats]*/) {
+    for (int i = 0; i < kPolyTabFloats; ++i) tab[i] = 0.f;
+    for (int k = 0; k < 6; ++k) {
+        tab[k * 48] = intercept[k];
+        for (int q = 0; q < 34; ++q) tab[k * 48 + 1 + q] = coef[k * 34 + q];
+        for (int v = 0; v < 4; ++v)
+            for (int q = 0; q < 15; ++q) tab[(18 + k * 4 + v) * 16 + q] = grad[(k * 4 + v) * 15 + q];
+    }
+}
 
 template <class T> struct AeroPre {
     T vr[3], V, alpha, beta, qbar;
@@ -137,9 +202,22 @@ template <int N> AC_DI void aero_pre(const DevParams& P, const Dual<N> x[13], Ae
 // the 34 monomials as duals costs 170 registers per evaluation point and made the sensitivity kernel spill 1 KB/lane.)
 // (For plain floats the monomials are cheap to hold — 34 registers — and building them first leaves the compiler a
 // shorter dependent chain: the forward kernels keep that form.)
-template <int NOUT>
-AC_DI void poly_eval(const DevParams& P, const int (&ks)[NOUT], const float f[4], float out[NOUT]) {
-    float m[34];
+// fit k over the 34 monomials mseq (f, pairs, triples in sklearn order): part 0 consumes the intercept and the first 31
+// coefficients (two table rows), part 1 the last three (one row)
+AC_DI float poly_value_part(int part, const Row16& r0, const Row16& r1, const float mseq[34], float acc) {
+    if (part == 0) {
+        acc = r0.c[0];
+#pragma unroll
+        for (int q = 0; q < 15; ++q) acc = fmaf(r0.c[1 + q], mseq[q], acc);
+#pragma unroll
+        for (int q = 15; q < 31; ++q) acc = fmaf(r1.c[q - 15], mseq[q], acc);
+    } else {
+#pragma unroll
+        for (int q = 31; q < 34; ++q) acc = fmaf(r0.c[q - 31], mseq[q], acc);
+    }
+    return acc;
+}
+AC_DI void poly_monomials(const float f[4], float m[34]) {
     int t = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) m[t++] = f[i];
@@ -154,22 +232,42 @@ AC_DI void poly_eval(const DevParams& P, const int (&ks)[NOUT], const float f[4]
         for (int j = i; j < 4; ++j)
 #pragma unroll
             for (int k = j; k < 4; ++k) m[t++] = m2[i][j] * f[k];
+}
+template <int NOUT>
+AC_DI void poly_eval(const DevParams& P, const int (&ks)[NOUT], const float f[4], float out[NOUT]) {
+    const PolyTab tab(P);
+    float m[34];
+    poly_monomials(f, m);
+    // items: (fit o, part p), o-major; rows of item i + 1 are requested before item i is consumed
+    Row16 c0 = tab.row(PolyTab::value_row(ks[0], 0)), c1 = tab.row(PolyTab::value_row(ks[0], 1));
+    PolyTab::arrive(c0, c1);
+    float acc = 0.f;
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) {
-        float acc = P.poly_intercept[ks[o]];
-#pragma unroll
-        for (int q = 0; q < 34; ++q) acc = acc + P.poly_coef[ks[o] * 34 + q] * m[q];
-        out[o] = acc;
+    for (int i = 0; i < 2 * NOUT; ++i) {
+        const int o = i >> 1, part = i & 1;
+        Row16 n0 = c0, n1 = c1;
+        if (i + 1 < 2 * NOUT) {
+            const int on = (i + 1) >> 1, pn = (i + 1) & 1;
+            n0 = tab.row(PolyTab::value_row(ks[on], pn == 0 ? 0 : 2));
+            if (pn == 0) n1 = tab.row(PolyTab::value_row(ks[on], 1));
+        }
+        acc = poly_value_part(part, c0, c1, m, acc);
+        AC_OPAQUE_V(acc);  // (computed HERE: otherwise the chain is sunk to its first use, and the rows wait for it in vector lanes)
+        if (part == 1) out[o] = acc;
+        AC_SCHED_FENCE();  // the chain above stays between the request and the wait of the next rows
+        if (i + 1 < 2 * NOUT) PolyTab::arrive(n0, n1);
+        c0 = n0; c1 = n1;
     }
 }
 template <int NOUT, class T>
 AC_DI void poly_eval(const DevParams& P, const int (&ks)[NOUT], const T f[4], T out[NOUT]) {
+    const PolyTab tab(P);
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) out[o] = T(P.poly_intercept[ks[o]]);
+    for (int o = 0; o < NOUT; ++o) out[o] = T(tab.intercept(ks[o]));
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) out[o] = out[o] + P.poly_coef[ks[o] * 34 + i] * f[i];
+        for (int o = 0; o < NOUT; ++o) out[o] = out[o] + tab.coef(ks[o], i) * f[i];
     int t2 = 4, t3 = 14;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -177,25 +275,25 @@ AC_DI void poly_eval(const DevParams& P, const int (&ks)[NOUT], const T f[4], T 
         for (int j = i; j < 4; ++j) {
             const T m2 = f[i] * f[j];
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) out[o] = out[o] + P.poly_coef[ks[o] * 34 + t2] * m2;
+            for (int o = 0; o < NOUT; ++o) out[o] = out[o] + tab.coef(ks[o], t2) * m2;
             ++t2;
 #pragma unroll
             for (int k = j; k < 4; ++k) {
                 const T m3 = m2 * f[k];
 #pragma unroll
-                for (int o = 0; o < NOUT; ++o) out[o] = out[o] + P.poly_coef[ks[o] * 34 + t3] * m3;
+                for (int o = 0; o < NOUT; ++o) out[o] = out[o] + tab.coef(ks[o], t3) * m3;
                 ++t3;
             }
         }
 }
 // P_CZ(alpha, 0, 0, 0): only the pure-alpha monomials survive (terms 0, 4, 14)
 template <class T> AC_DI T poly_cz_alpha_only(const DevParams& P, const T& al) {
+    const PolyTab tab(P);
     const T a2 = al * al;
-    return T(P.poly_intercept[2]) + P.poly_coef[2 * 34 + 0] * al + P.poly_coef[2 * 34 + 4] * a2 +
-           P.poly_coef[2 * 34 + 14] * (a2 * al);
+    return T(tab.intercept(2)) + tab.coef(2, 0) * al + tab.coef(2, 4) * a2 + tab.coef(2, 14) * (a2 * al);
 }
 
-// Host side of DevParams::poly_grad (ac_set_poly; tests/host_dyn): every monomial of sklearn's degree-<=3 basis over four
+// Host side of the grad part of DevParams::poly_tab (ac_set_poly; tests/host_dyn): every monomial of sklearn's degree-<=3 basis over four
 // features, differentiated with respect to f_v, lands on one element of the degree-<=2 basis with its multiplicity.
 inline void poly_gradient_tables(const float* coef /*[6][34]*/, float* grad /*[6][4][15]*/) {
     auto basis2 = [](int a, int b) {  // index of f_a f_b (a <= b) in [1, f_0..f_3, pairs...]
@@ -231,45 +329,53 @@ inline void poly_gradient_tables(const float* coef /*[6][34]*/, float* grad /*[6
 // multiply-adds per fit, every coefficient a scalar operand.
 template <int NOUT>
 AC_DI void poly_value_grad(const DevParams& P, const int (&ks)[NOUT], const float f[4], float val[NOUT], float grad[NOUT][4]) {
-    float m2[10], m3[20];
-    int t = 0;
+    const PolyTab tab(P);
+    float m[34];
+    poly_monomials(f, m);
+    // items 0 .. 2 NOUT - 1: two gradient chains each (fit o, variables 2 h and 2 h + 1: 15 fused multiply-adds over 1, f, pairs);
+    // items 2 NOUT .. 4 NOUT - 1: the value chain of fit o in two parts.  Two table rows per item, the next item's rows are
+    // requested before the current item is consumed and waited for after it: at most four rows
+    // (64 scalar registers) are ever live — left to itself the compiler requests every row of an evaluation point at
+    // once and spills the scalar registers into vector lanes.
+    constexpr int NI = 4 * NOUT;
+    Row16 c0 = tab.row(PolyTab::grad_row(ks[0], 0)), c1 = tab.row(PolyTab::grad_row(ks[0], 1));
+    PolyTab::arrive(c0, c1);
+    float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = i; j < 4; ++j) m2[t++] = f[i] * f[j];
-    t = 0;
-    int t2 = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = i; j < 4; ++j) {
-#pragma unroll
-            for (int k = j; k < 4; ++k) m3[t++] = m2[t2] * f[k];
-            ++t2;
+    for (int i = 0; i < NI; ++i) {
+        Row16 n0 = c0, n1 = c1;
+        if (i + 1 < NI) {
+            const int in = i + 1;
+            if (in < 2 * NOUT) {
+                n0 = tab.row(PolyTab::grad_row(ks[in >> 1], 2 * (in & 1)));
+                n1 = tab.row(PolyTab::grad_row(ks[in >> 1], 2 * (in & 1) + 1));
+            } else {
+                const int on = (in - 2 * NOUT) >> 1, pn = (in - 2 * NOUT) & 1;
+                n0 = tab.row(PolyTab::value_row(ks[on], pn == 0 ? 0 : 2));
+                if (pn == 0) n1 = tab.row(PolyTab::value_row(ks[on], 1));
+            }
         }
+        if (i < 2 * NOUT) {
+            const int o = i >> 1, v = 2 * (i & 1);
+            float g0 = c0.c[0], g1 = c1.c[0];
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) {
-        const float* c = &P.poly_coef[ks[o] * 34];
-        float acc = P.poly_intercept[ks[o]];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc = fmaf(c[q], f[q], acc);
-#pragma unroll
-        for (int q = 0; q < 10; ++q) acc = fmaf(c[4 + q], m2[q], acc);
-#pragma unroll
-        for (int q = 0; q < 20; ++q) acc = fmaf(c[14 + q], m3[q], acc);
-        val[o] = acc;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float* g = &P.poly_grad[(ks[o] * 4 + v) * 15];
-            float ga = g[0];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ga = fmaf(g[1 + q], f[q], ga);
-#pragma unroll
-            for (int q = 0; q < 10; ++q) ga = fmaf(g[5 + q], m2[q], ga);
-            grad[o][v] = ga;
+            for (int q = 0; q < 14; ++q) { g0 = fmaf(c0.c[1 + q], m[q], g0); g1 = fmaf(c1.c[1 + q], m[q], g1); }
+            AC_OPAQUE_V(g0); AC_OPAQUE_V(g1);  // (computed HERE: see poly_eval)
+            grad[o][v] = g0; grad[o][v + 1] = g1;
+        } else {
+            const int o = (i - 2 * NOUT) >> 1, part = (i - 2 * NOUT) & 1;
+            acc = poly_value_part(part, c0, c1, m, acc);
+            AC_OPAQUE_V(acc);
+            if (part == 1) val[o] = acc;
         }
+        AC_SCHED_FENCE();  // the chains above stay between the request and the wait of the next rows
+        if (i + 1 < NI) PolyTab::arrive(n0, n1);
+        c0 = n0; c1 = n1;
     }
 }
+
+// differentials of the aerodynamic inputs along one tangent direction (what a coefficient model's tangent() consumes)
+struct AeroD { float vr[3], alpha, beta, qbar, w[3], da, de, dr; };
 
 // Coefficient-provider protocol:
 //   prefetch(P, x, uv)      called on the stage state BEFORE anything else of the stage is computed; the MLP
@@ -279,102 +385,102 @@ AC_DI void poly_value_grad(const DevParams& P, const int (&ks)[NOUT], const floa
 template <int MODEL> struct AnalyticCoeffs {
     static constexpr int kModel = MODEL;
     template <class T> AC_DI void prefetch(const DevParams&, const T*, const float*) {}
-    // First-order duals: the model's partial derivatives are formed once on the primal (closed forms; for the cubic fits
-    // value and gradient from the host-derived tables) and every direction is one short chain-rule row.
-    template <int N>
-    AC_DI void operator()(const DevParams& P, const AeroPre<Dual<N>>& a, const Dual<N> x[13], const Dual<N> u[7],
-                          Dual<N> C[6]) const {
-        typedef Dual<N> T;
-        const T* w = &x[10];
-        const T &da = u[0], &de = u[1], &dr = u[2];
-        if constexpr (MODEL == AC_MODEL_LINEAR) {
-            const T* in[5] = {&a.qbar, &a.alpha, &a.beta, &da, &de};
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                T s = P.linear_W[k * 6 + 0] * (*in[0]);
-#pragma unroll
-                for (int j = 1; j < 5; ++j) s = dual_axpy(P.linear_W[k * 6 + j], *in[j], s);
-                C[k] = s + P.linear_W[k * 6 + 5];
-            }
-            C[5] = dual_axpy(-0.1f * 6.0f * kDeg, dr, C[5]);
-        } else if constexpr (MODEL == AC_MODEL_POLY) {
+    // First-order tangents, one direction at a time (state_derivative for duals, below): linearise() evaluates the model on
+    // the primal and keeps its partial derivatives (closed forms; for the cubic fits value and gradient from the
+    // host-derived tables), tangent() is the chain-rule row of one direction.
+    static constexpr bool kFusedTangent = true;
+    struct NoLin {};
+    struct PolyLin { float g4[4][4], ge[4], gr[4], cey, cex, cly, clx, cry, crx, kb0, kb2, kby, sr, sl, arm, b4; };
+    struct DefaultLin { float c0; };
+    typename std::conditional<MODEL == AC_MODEL_POLY, PolyLin,
+                              typename std::conditional<MODEL == AC_MODEL_DEFAULT, DefaultLin, NoLin>::type>::type lin;
+
+    AC_DI void linearise(const DevParams& P, const AeroPre<float>& a, const float x[13], const float u[7], float C[6]) {
+        if constexpr (MODEL == AC_MODEL_POLY) {
+            const float* w = &x[10];
             const float eps = P.p.epsilon, arm = P.p.rudder_moment_arm, b4 = P.p.b * 0.25f;
-            const float v0 = a.vr[0].v, v1 = a.vr[1].v, v2 = a.vr[2].v;
+            const float v0 = a.vr[0], v1 = a.vr[1], v2 = a.vr[2];
             const float ux = v0 + eps;
             // effective angles (aircraft.py:189-233) with the coefficients of their differentials
-            const float ye = fmaf(arm, w[1].v, v2), yl = fmaf(-b4, w[0].v, v2), yr = fmaf(b4, w[0].v, v2);
+            const float ye = v2 + arm * w[1], yl = v2 - b4 * w[0], yr = v2 + b4 * w[0];
             const float alpha_e = atan2f(ye, ux), alpha_l = atan2f(yl, ux), alpha_r = atan2f(yr, ux);
             const float de_ = 1.0f / fmaf(ux, ux, ye * ye), dl_ = 1.0f / fmaf(ux, ux, yl * yl), dr_ = 1.0f / fmaf(ux, ux, yr * yr);
-            const float vy = fmaf(-arm, w[2].v, v1);
+            const float vy = v1 - arm * w[2];
             const float nb = sqrtf(v0 * v0 + vy * vy + v2 * v2 + eps);
             const float tb = vy / nb;
             const float beta_r = asinf(tb);
             const float gb = (1.0f / nb) / sqrtf(fmaf(-tb, tb, 1.0f));
             const float kb = gb * tb / nb;  // d beta_r = gb d vy - kb (v0 d v0 + vy d vy + v2 d v2)
-            float val4[4], g4[4][4], vale[1], ge[1][4], valr[1], gr[1][4];
+            float val4[4], vale[1], valr[1], ge[1][4], gr[1][4];
             {
-                const float f[4] = {a.alpha.v, a.beta.v, da.v, de.v};
+                const float f[4] = {a.alpha, a.beta, u[0], u[1]};
                 const int ks[4] = {0, 1, 2, 3};
-                poly_value_grad<4>(P, ks, f, val4, g4);
+                poly_value_grad<4>(P, ks, f, val4, lin.g4);
             }
             {
-                const float f[4] = {alpha_e, a.beta.v, da.v, de.v};
+                const float f[4] = {alpha_e, a.beta, u[0], u[1]};
                 const int ks[1] = {4};
                 poly_value_grad<1>(P, ks, f, vale, ge);
             }
             {
-                const float f[4] = {a.alpha.v, beta_r, da.v, de.v};
+                const float f[4] = {a.alpha, beta_r, u[0], u[1]};
                 const int ks[1] = {5};
                 poly_value_grad<1>(P, ks, f, valr, gr);
             }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { lin.ge[v] = ge[0][v]; lin.gr[v] = gr[0][v]; }
             // P_CZ(alpha_x, 0, 0, 0) and its slope
-            const float z0 = P.poly_intercept[2], z1 = P.poly_coef[2 * 34 + 0], z2 = P.poly_coef[2 * 34 + 4], z3 = P.poly_coef[2 * 34 + 14];
+            const PolyTab tab(P);
+            const float z0 = tab.intercept(2), z1 = tab.coef(2, 0), z2 = tab.coef(2, 4), z3 = tab.coef(2, 14);
             const float czr = fmaf(fmaf(fmaf(z3, alpha_r, z2), alpha_r, z1), alpha_r, z0);
             const float czl = fmaf(fmaf(fmaf(z3, alpha_l, z2), alpha_l, z1), alpha_l, z0);
             const float hb = b4 * 0.5f;
-            const float sr = hb * fmaf(fmaf(3.0f * z3, alpha_r, z2 + z2), alpha_r, z1);
-            const float sl = -(hb * fmaf(fmaf(3.0f * z3, alpha_l, z2 + z2), alpha_l, z1));
+            lin.sr = hb * fmaf(fmaf(3.0f * z3, alpha_r, z2 + z2), alpha_r, z1);
+            lin.sl = -(hb * fmaf(fmaf(3.0f * z3, alpha_l, z2 + z2), alpha_l, z1));
 #pragma unroll
-            for (int k = 0; k < 4; ++k) C[k].v = val4[k];
-            C[3].v = fmaf(hb, czr - czl, C[3].v);
-            C[4].v = vale[0];
-            C[5].v = fmaf(0.01f * 6.0f * kDeg, dr.v, valr[0]);
+            for (int k = 0; k < 4; ++k) C[k] = val4[k];
+            C[3] = fmaf(hb, czr - czl, C[3]);
+            C[4] = vale[0];
+            C[5] = fmaf(0.01f * 6.0f * kDeg, u[2], valr[0]);
             // d alpha_x = cx_y d y_x + cx_x d v0
-            const float cey = ux * de_, cex = -(ye * de_), cly = ux * dl_, clx = -(yl * dl_), cry = ux * dr_, crx = -(yr * dr_);
-            const float kb0 = -(kb * v0), kb2 = -(kb * v2), kby = fmaf(-kb, vy, gb);
+            lin.cey = ux * de_; lin.cex = -(ye * de_); lin.cly = ux * dl_; lin.clx = -(yl * dl_);
+            lin.cry = ux * dr_; lin.crx = -(yr * dr_);
+            lin.kb0 = -(kb * v0); lin.kb2 = -(kb * v2); lin.kby = fmaf(-kb, vy, gb);
+            lin.arm = arm; lin.b4 = b4;
+        } else {
+            (*this)(P, a, x, u, C);  // the forward kernels' expressions
+            if constexpr (MODEL == AC_MODEL_DEFAULT) lin.c0 = -0.6f * a.alpha;
+        }
+    }
+    AC_DI void tangent(const DevParams& P, const AeroD& d, float dC[6]) const {
+        if constexpr (MODEL == AC_MODEL_LINEAR) {
+            const float in[5] = {d.qbar, d.alpha, d.beta, d.da, d.de};
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                const float d0 = a.vr[0].d[j], d1 = a.vr[1].d[j], d2 = a.vr[2].d[j];
-                const float dal = a.alpha.d[j], dbe = a.beta.d[j], dda = da.d[j], dde = de.d[j];
-                const float dae = fmaf(cey, fmaf(arm, w[1].d[j], d2), cex * d0);
-                const float dalp = fmaf(cly, fmaf(-b4, w[0].d[j], d2), clx * d0);
-                const float darp = fmaf(cry, fmaf(b4, w[0].d[j], d2), crx * d0);
-                const float dbr = fmaf(kby, fmaf(-arm, w[2].d[j], d1), fmaf(kb0, d0, kb2 * d2));
+            for (int k = 0; k < 6; ++k) {
+                float t = P.linear_W[k * 6 + 0] * in[0];
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    C[k].d[j] = fmaf(g4[k][0], dal, fmaf(g4[k][1], dbe, fmaf(g4[k][2], dda, g4[k][3] * dde)));
-                C[3].d[j] = fmaf(sr, darp, fmaf(sl, dalp, C[3].d[j]));
-                C[4].d[j] = fmaf(ge[0][0], dae, fmaf(ge[0][1], dbe, fmaf(ge[0][2], dda, ge[0][3] * dde)));
-                C[5].d[j] = fmaf(gr[0][0], dal, fmaf(gr[0][1], dbr, fmaf(gr[0][2], dda, fmaf(gr[0][3], dde, (0.01f * 6.0f * kDeg) * dr.d[j]))));
+                for (int j = 1; j < 5; ++j) t = fmaf(P.linear_W[k * 6 + j], in[j], t);
+                dC[k] = t;
             }
+            dC[5] = fmaf(-0.1f * 6.0f * kDeg, d.dr, dC[5]);
+        } else if constexpr (MODEL == AC_MODEL_POLY) {
+            const float dae = fmaf(lin.cey, fmaf(lin.arm, d.w[1], d.vr[2]), lin.cex * d.vr[0]);
+            const float dal = fmaf(lin.cly, fmaf(-lin.b4, d.w[0], d.vr[2]), lin.clx * d.vr[0]);
+            const float dar = fmaf(lin.cry, fmaf(lin.b4, d.w[0], d.vr[2]), lin.crx * d.vr[0]);
+            const float dbr = fmaf(lin.kby, fmaf(-lin.arm, d.w[2], d.vr[1]), fmaf(lin.kb0, d.vr[0], lin.kb2 * d.vr[2]));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                dC[k] = fmaf(lin.g4[k][0], d.alpha, fmaf(lin.g4[k][1], d.beta, fmaf(lin.g4[k][2], d.da, lin.g4[k][3] * d.de)));
+            dC[3] = fmaf(lin.sr, dar, fmaf(lin.sl, dal, dC[3]));
+            dC[4] = fmaf(lin.ge[0], dae, fmaf(lin.ge[1], d.beta, fmaf(lin.ge[2], d.da, lin.ge[3] * d.de)));
+            dC[5] = fmaf(lin.gr[0], d.alpha, fmaf(lin.gr[1], dbr, fmaf(lin.gr[2], d.da, fmaf(lin.gr[3], d.de, (0.01f * 6.0f * kDeg) * d.dr))));
         } else {  // DefaultModel
-            const float al = a.alpha.v;
-            C[0].v = -(0.02f + 0.3f * (al * al));
-            C[1].v = -0.98f * a.beta.v;
-            C[2].v = -(5.0f * al);
-            C[3].v = (0.08f * 4.0f * kDeg) * da.v + (-0.05f) * w[0].v;
-            C[4].v = (-1.2f * 5.0f * kDeg) * de.v + (-0.5f) * w[1].v;
-            C[5].v = (-0.1f * 6.0f * kDeg) * dr.v + (-0.05f) * w[2].v;
-            const float c0 = -0.6f * al;
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                C[0].d[j] = c0 * a.alpha.d[j];
-                C[1].d[j] = -0.98f * a.beta.d[j];
-                C[2].d[j] = -5.0f * a.alpha.d[j];
-                C[3].d[j] = fmaf(0.08f * 4.0f * kDeg, da.d[j], -0.05f * w[0].d[j]);
-                C[4].d[j] = fmaf(-1.2f * 5.0f * kDeg, de.d[j], -0.5f * w[1].d[j]);
-                C[5].d[j] = fmaf(-0.1f * 6.0f * kDeg, dr.d[j], -0.05f * w[2].d[j]);
-            }
+            dC[0] = lin.c0 * d.alpha;
+            dC[1] = -0.98f * d.beta;
+            dC[2] = -5.0f * d.alpha;
+            dC[3] = fmaf(0.08f * 4.0f * kDeg, d.da, -0.05f * d.w[0]);
+            dC[4] = fmaf(-1.2f * 5.0f * kDeg, d.de, -0.5f * d.w[1]);
+            dC[5] = fmaf(-0.1f * 6.0f * kDeg, d.dr, -0.05f * d.w[2]);
         }
     }
     template <class T>
@@ -636,6 +742,190 @@ AC_DI void state_derivative(const DevParams& P, Coeffs& coeffs, const T x[13], c
     rigid_body(P, x, o, xd);
 }
 
+// x_dot with first-order tangents.  Providers that implement linearise() / tangent() (the analytic models) take the FUSED
+// form: everything that depends on the primal only — the forward kernels' own expressions for the values, and the
+// coefficients of every differential — is formed once; then each direction runs from (dv, dq, d omega, du) to d x_dot on
+// its own, so no N-wide intermediate (relative velocity, angles, coefficients, forces, moments: 88 registers at N = 4)
+// is live between phases.  Other providers keep the phase structure above (overloads of aero_pre, aero_post, rigid_body).
+template <class C, class = void> struct fused_tangent : std::false_type {};
+template <class C> struct fused_tangent<C, typename std::enable_if<C::kFusedTangent>::type> : std::true_type {};
+
+template <int N, class Coeffs>
+AC_DI void state_derivative(const DevParams& P, Coeffs& coeffs, const Dual<N> x[13], const Dual<N> u[7], Dual<N> xd[13]) {
+    if constexpr (!fused_tangent<Coeffs>::value || Coeffs::kModel == AC_MODEL_QUAD) {
+        state_derivative<Dual<N>, Coeffs>(P, coeffs, x, u, xd);
+    } else {
+        const float eps = P.p.epsilon;
+        float xv[13], uv[7];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) xv[i] = x[i].v;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) uv[i] = u[i].v;
+        // ---- values: the float path ----
+        AeroPre<float> a;
+        aero_pre(P, xv, a);
+        float C[6];
+#ifdef AC_PROBE_NOLIN
+        for (int k = 0; k < 6; ++k) C[k] = a.alpha * (float)k;
+#else
+        coeffs.linearise(P, a, xv, uv, C);
+#endif
+        // stall factors (dynamics/aircraft.py:280-294) as coefficients of (dC, d alpha, d beta)
+        float s2 = 1.f, k2a = 0.f, k2b = 0.f, s4 = 1.f, k4a = 0.f;
+        if (P.p.stall_scaling) {
+            const float lim = 30.0f * kDeg, steep = 10.0f;
+            const float ea = expf(steep * (fabsf(a.alpha) - lim)), eb = expf(steep * (fabsf(a.beta) - lim));
+            const float sa = 1.0f / (1.0f + ea), sb = 1.0f / (1.0f + eb);
+            const float dsa = -(sa * sa) * ea * (a.alpha < 0.f ? -steep : steep);
+            const float dsb = -(sb * sb) * eb * (a.beta < 0.f ? -steep : steep);
+            s2 = sa * sb; s4 = sa;
+            k2a = C[2] * sb * dsa; k2b = C[2] * sa * dsb; k4a = C[4] * dsa;
+        }
+        AeroPost<float> o;
+        aero_post(P, a, uv, C, o);  // (applies stall and flaps to C)
+        float xdv[13];
+        rigid_body(P, xv, o, xdv);
+#pragma unroll
+        for (int i = 0; i < 13; ++i) xd[i].v = xdv[i];
+        // ---- tangents: per direction  (dv, dq, d omega, du) -> differentials of the aerodynamic inputs -> dC -> (dF, dM)
+        // -> d x_dot.  Light models run a direction through all of it at once (no N-wide intermediate at all); the cubic
+        // fits, whose 39 gradient coefficients would be live beside every other coefficient set (about 110 registers held
+        // across the whole loop), run it as four passes separated by scheduling fences, each pass forming its own
+        // coefficients behind the fence so that they are live for that pass only.
+        constexpr bool kPasses = Coeffs::kModel == AC_MODEL_POLY;
+        const Q4<float> q{xv[6], xv[7], xv[8], xv[9]};
+        const Q4<float> qi = qinv(q);
+        AeroD dd[kPasses ? N : 1];
+        float dCC[kPasses ? N : 1][6], dFM[kPasses ? N : 1][6];
+        if constexpr (kPasses) AC_SCHED_FENCE();
+        {
+            // (a) differentials of the aerodynamic inputs
+            const Q4<float> r = qmul(qmul_vec(qi, xv[3], xv[4], xv[5]), q);
+            const Rot3 R = rot_inverse(q, qi);
+            const float r2[3] = {r.x + r.x, r.y + r.y, r.z + r.z};
+            const float v0 = a.vr[0], v1 = a.vr[1], v2 = a.vr[2];
+            const float ux = v0 + eps;
+            const float den = 1.0f / fmaf(ux, ux, v2 * v2);
+            const float ca_y = ux * den, ca_x = -(v2 * den);        // d alpha = ca_y d v2 + ca_x d v0
+            const float tb = v1 / a.V;
+            const float gb = (1.0f / a.V) / sqrtf(fmaf(-tb, tb, 1.0f));
+            const float gbv = -(gb * tb) * (0.5f / a.V);            // d beta = gb d v1 + gbv d(v.v)
+            const float w0 = v0 + v0, w1 = v1 + v1, w2 = v2 + v2;   // d(v.v) = 2 v . dv
+            auto aero_d = [&](int j, AeroD& d) {
+                const float dv0 = x[3].d[j], dv1 = x[4].d[j], dv2 = x[5].d[j];
+                const float dqx = x[6].d[j], dqy = x[7].d[j], dqz = x[8].d[j], dqw = x[9].d[j];
+                // vector part of q^-1 dq:  bw dq_v + dq_w b + b x dq_v
+                const float tx = fmaf(qi.w, dqx, dqw * qi.x), ty = fmaf(qi.w, dqy, dqw * qi.y), tz = fmaf(qi.w, dqz, dqw * qi.z);
+                const float cx = fmaf(qi.y, dqz, -(qi.z * dqy)), cy = fmaf(qi.z, dqx, -(qi.x * dqz)), cz = fmaf(qi.x, dqy, -(qi.y * dqx));
+                const float e0 = tx + cx, e1 = ty + cy, e2 = tz + cz;
+                d.vr[0] = fmaf(R.m[0][0], dv0, fmaf(R.m[0][1], dv1, fmaf(R.m[0][2], dv2, fmaf(r2[1], e2, -(r2[2] * e1)))));
+                d.vr[1] = fmaf(R.m[1][0], dv0, fmaf(R.m[1][1], dv1, fmaf(R.m[1][2], dv2, fmaf(r2[2], e0, -(r2[0] * e2)))));
+                d.vr[2] = fmaf(R.m[2][0], dv0, fmaf(R.m[2][1], dv1, fmaf(R.m[2][2], dv2, fmaf(r2[0], e1, -(r2[1] * e0)))));
+                const float dvv = fmaf(w0, d.vr[0], fmaf(w1, d.vr[1], w2 * d.vr[2]));
+                d.alpha = fmaf(ca_y, d.vr[2], ca_x * d.vr[0]);
+                d.beta = fmaf(gb, d.vr[1], gbv * dvv);
+                d.qbar = (0.5f * 1.225f) * dvv;
+                d.w[0] = x[10].d[j]; d.w[1] = x[11].d[j]; d.w[2] = x[12].d[j];
+                d.da = u[0].d[j]; d.de = u[1].d[j]; d.dr = u[2].d[j];
+            };
+            // (b) the model's chain-rule row, stall factors, flaps
+            auto coeff_d = [&](int j, const AeroD& d, float dC[6]) {
+                coeffs.tangent(P, d, dC);
+                if (P.p.stall_scaling) {
+                    dC[2] = fmaf(s2, dC[2], fmaf(k2a, d.alpha, k2b * d.beta));
+                    dC[4] = fmaf(s4, dC[4], k4a * d.alpha);
+                }
+                const float dfl = u[6].d[j];
+                dC[0] = fmaf(-0.1f, dfl, dC[0]);
+                dC[2] = fmaf(-0.6f, dfl, dC[2]);
+            };
+            // (c) d F_k = sign (C_k S d qbar + qS d C_k),  d Ma_k = len_k (C_{3+k} S d qbar + qS d C_{3+k}),  d M = d Ma + com x d F
+            auto post_d = [&](float dqbar, const float dC[6], float fm[6]) {
+                const float S = P.p.S;
+                const float qS = a.qbar * S;
+                const float sg = sign_of(a.vr[0]);
+                const float len[3] = {P.p.b, P.p.c, P.p.b};
+                const float* com = P.p.com;
+                float dM[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float sc = k == 0 ? sg : 1.0f;
+                    fm[k] = fmaf(C[k] * S * sc, dqbar, (qS * sc) * dC[k]);
+                    dM[k] = fmaf(C[3 + k] * S * len[k], dqbar, (qS * len[k]) * dC[3 + k]);
+                }
+                fm[3] = fmaf(com[1], fm[2], fmaf(-com[2], fm[1], dM[0]));
+                fm[4] = fmaf(com[2], fm[0], fmaf(-com[0], fm[2], dM[1]));
+                fm[5] = fmaf(com[0], fm[1], fmaf(-com[1], fm[0], dM[2]));
+            };
+            if constexpr (kPasses) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) aero_d(j, dd[j]);
+                AC_SCHED_FENCE();
+#pragma unroll
+                for (int j = 0; j < N; ++j) coeff_d(j, dd[j], dCC[j]);
+                AC_SCHED_FENCE();
+#pragma unroll
+                for (int j = 0; j < N; ++j) post_d(dd[j].qbar, dCC[j], dFM[j]);
+                AC_SCHED_FENCE();
+            }
+            // (d) rigid body: forces_ned by the closed form of the rotation, quaternion kinematics, Euler's equation
+            const float im = 1.0f / P.p.mass;
+            const Q4<float> Fn = qmul(qmul_vec(q, o.F[0], o.F[1], o.F[2]), qi);
+            float Rm[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) Rm[i][k] = R.m[k][i] * im;
+            const float im2 = im + im;
+            const float f2[3] = {Fn.x * im2, Fn.y * im2, Fn.z * im2};
+            const float om0 = xv[10], om1 = xv[11], om2 = xv[12];
+            const float hw0 = 0.5f * om0, hw1 = 0.5f * om1, hw2 = 0.5f * om2;
+            const Q4<float> hq{0.5f * q.x, 0.5f * q.y, 0.5f * q.z, 0.5f * q.w};
+            const float* I = P.p.inertia;
+            const float* Ii = P.p.inertia_inv;
+            float Iw[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) Iw[i] = I[3 * i] * om0 + I[3 * i + 1] * om1 + I[3 * i + 2] * om2;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float fm[6];
+                if constexpr (kPasses) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) fm[k] = dFM[j][k];
+                } else {
+                    AeroD d;
+                    float dC[6];
+                    aero_d(j, d);
+                    coeff_d(j, d, dC);
+                    post_d(d.qbar, dC, fm);
+                }
+                const float dqx = x[6].d[j], dqy = x[7].d[j], dqz = x[8].d[j], dqw = x[9].d[j];
+                const float dw0 = x[10].d[j], dw1 = x[11].d[j], dw2 = x[12].d[j];
+                // vector part of dq q^-1:  bw dq_v + dq_w b - b x dq_v
+                const float tx = fmaf(qi.w, dqx, dqw * qi.x), ty = fmaf(qi.w, dqy, dqw * qi.y), tz = fmaf(qi.w, dqz, dqw * qi.z);
+                const float cx = fmaf(qi.y, dqz, -(qi.z * dqy)), cy = fmaf(qi.z, dqx, -(qi.x * dqz)), cz = fmaf(qi.x, dqy, -(qi.y * dqx));
+                const float p0 = tx - cx, p1 = ty - cy, p2 = tz - cz;
+                xd[0].d[j] = x[3].d[j]; xd[1].d[j] = x[4].d[j]; xd[2].d[j] = x[5].d[j];
+                xd[3].d[j] = fmaf(Rm[0][0], fm[0], fmaf(Rm[0][1], fm[1], fmaf(Rm[0][2], fm[2], fmaf(p1, f2[2], -(p2 * f2[1])))));
+                xd[4].d[j] = fmaf(Rm[1][0], fm[0], fmaf(Rm[1][1], fm[1], fmaf(Rm[1][2], fm[2], fmaf(p2, f2[0], -(p0 * f2[2])))));
+                xd[5].d[j] = fmaf(Rm[2][0], fm[0], fmaf(Rm[2][1], fm[1], fmaf(Rm[2][2], fm[2], fmaf(p0, f2[1], -(p1 * f2[0])))));
+                xd[6].d[j] = fmaf(dqw, hw0, fmaf(dqy, hw2, fmaf(-dqz, hw1, fmaf(hq.w, dw0, fmaf(hq.y, dw2, -(hq.z * dw1))))));
+                xd[7].d[j] = fmaf(dqw, hw1, fmaf(dqz, hw0, fmaf(-dqx, hw2, fmaf(hq.w, dw1, fmaf(hq.z, dw0, -(hq.x * dw2))))));
+                xd[8].d[j] = fmaf(dqw, hw2, fmaf(dqx, hw1, fmaf(-dqy, hw0, fmaf(hq.w, dw2, fmaf(hq.x, dw1, -(hq.y * dw0))))));
+                xd[9].d[j] = -fmaf(dqx, hw0, fmaf(dqy, hw1, fmaf(dqz, hw2, fmaf(hq.x, dw0, fmaf(hq.y, dw1, hq.z * dw2)))));
+                float dIw[3], dr[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) dIw[i] = fmaf(I[3 * i], dw0, fmaf(I[3 * i + 1], dw1, I[3 * i + 2] * dw2));
+                dr[0] = fm[3] - fmaf(dw1, Iw[2], fmaf(om1, dIw[2], -fmaf(dw2, Iw[1], om2 * dIw[1])));
+                dr[1] = fm[4] - fmaf(dw2, Iw[0], fmaf(om2, dIw[0], -fmaf(dw0, Iw[2], om0 * dIw[2])));
+                dr[2] = fm[5] - fmaf(dw0, Iw[1], fmaf(om0, dIw[1], -fmaf(dw1, Iw[0], om1 * dIw[0])));
+#pragma unroll
+                for (int i = 0; i < 3; ++i) xd[10 + i].d[j] = fmaf(Ii[3 * i], dr[0], fmaf(Ii[3 * i + 1], dr[1], Ii[3 * i + 2] * dr[2]));
+            }
+        }
+    }
+}
+
 template <class T> AC_DI void normalise_q(T x[13]) {
     const T n = m_sqrt(x[6] * x[6] + x[7] * x[7] + x[8] * x[8] + x[9] * x[9]);
     const T inv = 1.0f / n;
@@ -745,18 +1035,59 @@ template <int N> struct SeedsT {
 };
 typedef SeedsT<4> Seeds;
 
+// Where the RK4 sum  k1 + 2 k2 + 2 k3 + k4  of a seeded step lives.  It is touched once per stage, so it need not occupy
+// registers across the stage evaluation:
+//   RegAcc<N>   registers (the MLP kernels: one wave per SIMD owns the whole register file anyway)
+//   LdsAcc4     N = 4: the 13 x 4 tangents as one 16-byte LDS word per row and lane (conflict-free b128 accesses, one
+//               read-modify-write per stage), the 13 values in registers — 52 registers less at the point of highest
+//               pressure, which is what lets the analytic kernels run two waves per SIMD without scratch
+template <int N> struct RegAcc {
+    Dual<N> a[13];
+    AC_DI void zero() {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) a[i] = Dual<N>(0.f);
+    }
+    AC_DI void add(int i, float w, const Dual<N>& k) { a[i] = dual_axpy(w, k, a[i]); }
+    AC_DI Dual<N> get(int i) const { return a[i]; }
+};
+#ifndef AC_HOST_CHECK
+struct LdsAcc4 {
+    float v[13];
+    float4* base;  // this lane's word of row 0; rows are `stride` words apart
+    int stride;
+    AC_DI LdsAcc4(float4* lane_word, int stride_) : base(lane_word), stride(stride_) {}
+    AC_DI void zero() {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) { v[i] = 0.f; base[i * stride] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+    AC_DI void add(int i, float w, const Dual<4>& k) {
+        v[i] = fmaf(w, k.v, v[i]);
+        float4 t = base[i * stride];
+        t.x = fmaf(w, k.d[0], t.x); t.y = fmaf(w, k.d[1], t.y); t.z = fmaf(w, k.d[2], t.z); t.w = fmaf(w, k.d[3], t.w);
+        base[i * stride] = t;
+    }
+    AC_DI Dual<4> get(int i) const {
+        Dual<4> r; r.v = v[i];
+        const float4 t = base[i * stride];
+        r.d[0] = t.x; r.d[1] = t.y; r.d[2] = t.z; r.d[3] = t.w;
+        return r;
+    }
+};
+#endif
+
 // One RK4 step from primal inputs; xo = F(x0, u, h) with tangents w.r.t. this lane's N directions.
-template <int N, class Coeffs>
+template <int N, class Coeffs, class Acc>
 AC_DI void rk4_step_seeded(const DevParams& P, Coeffs& coeffs, int g, const float xv[13], const float uv[7],
-                           float hv, float dh_ddt, Dual<N> xo[13]) {
+                           float hv, float dh_ddt, Dual<N> xo[13], Acc& acc) {
     typedef Dual<N> T;
     typedef SeedsT<N> Seeds;
-    T acc[13], xs[13], k[13];
+    T xs[13], k[13];
     {
         int g0 = g;
         AC_OPAQUE_V(g0);  // (likewise: not hoisted out of an enclosing sub-step / unit-group loop)
 #pragma unroll
-        for (int i = 0; i < 13; ++i) { xs[i] = Seeds::state(g0, i, xv[i]); acc[i] = T(0.f); }
+        for (int i = 0; i < 13; ++i) xs[i] = Seeds::state(g0, i, xv[i]);
+        acc.zero();
     }
 #pragma nounroll
     for (int s = 0; s < 4; ++s) {
@@ -773,7 +1104,7 @@ AC_DI void rk4_step_seeded(const DevParams& P, Coeffs& coeffs, int g, const floa
         const T hs = Seeds::step(gg, hv * cnext, dh_ddt * cnext);
 #pragma unroll
         for (int i = 0; i < 13; ++i) {
-            acc[i] = dual_axpy(wsum, k[i], acc[i]);
+            acc.add(i, wsum, k[i]);
             xs[i] = dual_mul_add(hs, k[i], Seeds::state(gg, i, xv[i]));
         }
     }
@@ -781,7 +1112,13 @@ AC_DI void rk4_step_seeded(const DevParams& P, Coeffs& coeffs, int g, const floa
     AC_OPAQUE_V(ge);  // the seeds of the final combination are rebuilt here, not carried across the four stages
     const T h6 = Seeds::step(ge, hv * (1.0f / 6.0f), dh_ddt * (1.0f / 6.0f));
 #pragma unroll
-    for (int i = 0; i < 13; ++i) xo[i] = dual_mul_add(h6, acc[i], Seeds::state(ge, i, xv[i]));
+    for (int i = 0; i < 13; ++i) xo[i] = dual_mul_add(h6, acc.get(i), Seeds::state(ge, i, xv[i]));
+}
+template <int N, class Coeffs>
+AC_DI void rk4_step_seeded(const DevParams& P, Coeffs& coeffs, int g, const float xv[13], const float uv[7],
+                           float hv, float dh_ddt, Dual<N> xo[13]) {
+    RegAcc<N> acc;
+    rk4_step_seeded<N>(P, coeffs, g, xv, uv, hv, dh_ddt, xo, acc);
 }
 
 }  // namespace ac

@@ -199,18 +199,25 @@ typedef SensIOT<4> SensIO;
 // substeps  > 1: each sub-step is seeded on its own (local Jacobian T_s w.r.t. its inputs) and composed with
 // the running total  T <- dF_s/dx . T + dF_s/d(u, dt)  kept in the OUTPUT arrays between sub-steps, so the
 // register footprint of the hot path is not paid for by the rare one.
-template <int N, class Coeffs>
+// SUB: 0 = the kernel handles any sub-step count (MLP kernels), 1 = one sub-step only (no composition code in the
+// kernel: its ~130 registers of told / tnew would otherwise set the allocation of the whole kernel), 2 = sub-stepped only.
+template <int N, int SUB = 0, class Coeffs, class Acc>
 AC_DI void sens_update(const DevParams& P, Coeffs& coeffs, int g, int col, const UnitAddr& ua, float xv[13],
                        const float uv[7], float dt, Dual<N> x[13], float* __restrict__ A, float* __restrict__ Bm,
-                       float* __restrict__ c, bool live) {
+                       float* __restrict__ c, bool live, Acc& acc) {
     constexpr int UPW = 4 * N;  // units per wave
     typedef SensIOT<N, Coeffs::kModel == AC_MODEL_QUAD> IO;
+    if constexpr (SUB == 1) {
+        rk4_step_seeded<N>(P, coeffs, g, xv, uv, dt, 1.0f, x, acc);
+        if (P.p.normalise) normalise_q(x);
+        return;
+    }
     const int ns = P.p.substeps < 1 ? 1 : P.p.substeps;
     const float hv = (ns == 1) ? dt : dt / (float)ns;
     const float dh = 1.0f / (float)ns;
 #pragma nounroll
     for (int s = 0; s < ns; ++s) {
-        rk4_step_seeded<N>(P, coeffs, g, xv, uv, hv, dh, x);
+        rk4_step_seeded<N>(P, coeffs, g, xv, uv, hv, dh, x, acc);
         if (ns > 1) {
             const UnitAddr ul = ua.late();  // addresses computed here, not hoisted to kernel entry
             if (s > 0) {
@@ -252,6 +259,14 @@ AC_DI void sens_update(const DevParams& P, Coeffs& coeffs, int g, int col, const
         }
     }
     if (P.p.normalise) normalise_q(x);
+}
+
+template <int N, class Coeffs>
+AC_DI void sens_update(const DevParams& P, Coeffs& coeffs, int g, int col, const UnitAddr& ua, float xv[13],
+                       const float uv[7], float dt, Dual<N> x[13], float* __restrict__ A, float* __restrict__ Bm,
+                       float* __restrict__ c, bool live) {
+    RegAcc<N> acc;
+    sens_update<N>(P, coeffs, g, col, ua, xv, uv, dt, x, A, Bm, c, live, acc);
 }
 
 // Directions per lane for the analytic models: four (four lanes per unit, 16 units per wave).  The kernels are bound by
@@ -551,7 +566,7 @@ __global__ __launch_bounds__(kBlock) void k_quat_rows(const float* __restrict__ 
     }
 }
 
-template <int MODEL>
+template <int MODEL, bool SUBSTEPPED>
 __global__ __launch_bounds__(kBlock, kSensWavesPerSimd) void k_step_sens(const DevParams P, const float* __restrict__ X,
                                                       const float* __restrict__ U, float dt,
                                                       const float* __restrict__ dt_per_unit, long n, long blk,
@@ -571,7 +586,10 @@ __global__ __launch_bounds__(kBlock, kSensWavesPerSimd) void k_step_sens(const D
     const float hv = dt_per_unit ? dt_per_unit[unit] : dt;
     Dual<kAnN> x[13];
     AnalyticCoeffs<MODEL> coeffs;
-    sens_update<kAnN>(P, coeffs, g, col, ua, xv, uv, hv, x, A, Bm, c, live);
+    static_assert(kAnN == 4, "LdsAcc4");
+    __shared__ float4 acc_words[13 * kBlock];  // 53 KB: two workgroups per CU
+    LdsAcc4 acc(&acc_words[threadIdx.x], kBlock);
+    sens_update<kAnN, SUBSTEPPED ? 2 : 1>(P, coeffs, g, col, ua, xv, uv, hv, x, A, Bm, c, live, acc);
     if (!live) return;
     const UnitAddr uo = ua.late();
     if (g == 0) {
@@ -581,5 +599,24 @@ __global__ __launch_bounds__(kBlock, kSensWavesPerSimd) void k_step_sens(const D
     }
     SensIOT<kAnN, MODEL == AC_MODEL_QUAD>::store(g, uo, x, A, Bm, c, true);
 }
+
+// The step + sensitivity and derivative + sensitivity kernels of the analytic models are compiled in a translation unit of
+// their own (an_inst_sens.hip, built with -fno-slp-vectorize: packing pairs of tangent chains into v_pk_fma_f32 costs the
+// two-waves-per-SIMD kernels more registers than they have — 300 B/lane of scratch for the cubic fits — and buys nothing
+// at that occupancy); every other unit only refers to them.
+#define AC_AN_SENS_ARGS const DevParams, const float*, const float*, float, const float*, long, long, float*, float*, float*, float*
+#define AC_AN_DERIV_ARGS const DevParams, const float*, const float*, long, long, float*, float*, float*
+#ifdef AC_AN_SENS_INSTANTIATE
+#define AC_AN_EXTERN
+#else
+#define AC_AN_EXTERN extern
+#endif
+#define AC_AN_MODEL(M)                                                            \
+    AC_AN_EXTERN template __global__ void k_step_sens<M, false>(AC_AN_SENS_ARGS); \
+    AC_AN_EXTERN template __global__ void k_step_sens<M, true>(AC_AN_SENS_ARGS);  \
+    AC_AN_EXTERN template __global__ void k_deriv_sens<M>(AC_AN_DERIV_ARGS);
+AC_AN_MODEL(AC_MODEL_DEFAULT) AC_AN_MODEL(AC_MODEL_LINEAR) AC_AN_MODEL(AC_MODEL_POLY) AC_AN_MODEL(AC_MODEL_QUAD)
+#undef AC_AN_MODEL
+#undef AC_AN_EXTERN
 
 }  // namespace ac

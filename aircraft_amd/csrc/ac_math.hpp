@@ -13,7 +13,17 @@
 #include <cmath>
 #define AC_DI inline
 #define AC_OPAQUE_V(x) ((void)0)
+#define AC_OPAQUE_S(x) ((void)0)
+#define AC_SCHED_FENCE() ((void)0)
+#define AC_CONSTANT
 #else
+// the same for a wave-uniform value (a pointer the loads behind it must not be hoisted past)
+#define AC_OPAQUE_S(x) asm volatile("" : "+s"(x))
+// constant address space: a uniform address in it is always read with scalar loads
+#define AC_CONSTANT __attribute__((address_space(4)))
+// the instruction scheduler moves nothing across this point (keeps a register-hungry primal phase from being interleaved
+// with the tangent phase that follows it)
+#define AC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #include <hip/hip_runtime.h>
 #define AC_DI __device__ __forceinline__
 // a copy of a per-lane value the optimiser cannot see through (keeps rebuilt 0/1 seed patterns out of long-lived registers)

@@ -92,6 +92,7 @@ struct ac_handle {
     size_t hess_ws_floats;
     float* d_hess_ws2;  // sub-step composition of the second-order blocks (substeps > 1)
     size_t hess_ws2_floats;
+    float* d_poly_tab;  // coefficient, intercept and gradient tables of the cubic fits (DevParams::poly_tab)
     float* d_track;  // [nseg][3][4] segment cubics (device)
     TrackDev track;
     // kernels whose dynamic-LDS limit was already raised on this handle's device (hipFuncSetAttribute is not free)
@@ -267,6 +268,7 @@ int ac_destroy(ac_handle* h) {
     if (h->d_vblob) (void)hipFree(h->d_vblob);
     if (h->d_queue) (void)hipFree(h->d_queue);
     if (h->d_track) (void)hipFree(h->d_track);
+    if (h->d_poly_tab) (void)hipFree(h->d_poly_tab);
     if (h->d_hess_ws) (void)hipFree(h->d_hess_ws);
     if (h->d_hess_ws2) (void)hipFree(h->d_hess_ws2);
     if (h->d_rev_scratch) (void)hipFree(h->d_rev_scratch);
@@ -291,9 +293,13 @@ int ac_set_linear(ac_handle* h, const float* W) {
 
 int ac_set_poly(ac_handle* h, const float* coef, const float* intercept) {
     if (!h || !coef || !intercept) return AC_ERR_BAD_ARG;
-    memcpy(h->dp.poly_coef, coef, sizeof(float) * 6 * 34);
-    memcpy(h->dp.poly_intercept, intercept, sizeof(float) * 6);
-    poly_gradient_tables(h->dp.poly_coef, h->dp.poly_grad);
+    AC_ENTER(h);
+    float tab[kPolyTabFloats], grad[6 * 4 * 15];
+    poly_gradient_tables(coef, grad);
+    poly_pack_tables(coef, intercept, grad, tab);
+    if (!h->d_poly_tab) AC_HIP(hipMalloc((void**)&h->d_poly_tab, sizeof(tab)));
+    AC_HIP(hipMemcpy(h->d_poly_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
+    h->dp.poly_tab = h->d_poly_tab;
     h->has_poly = true;
     return AC_OK;
 }
@@ -909,7 +915,22 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
     const int upb = 16 * (h->dp.p.model_kind == AC_MODEL_POLY ? AnalyticSensN<AC_MODEL_POLY>::value : AnalyticSensN<AC_MODEL_DEFAULT>::value);
     static_assert(AnalyticSensN<AC_MODEL_DEFAULT>::value == AnalyticSensN<AC_MODEL_LINEAR>::value, "grid size below");
     const int grid_an = (int)((n + upb - 1) / upb);
-    AC_LAUNCH_ANALYTIC(k_step_sens, grid_an, kBlock, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c);
+    // (sub-stepped updates: a kernel of its own, so that the composition code does not set the registers of the common one)
+    if (h->dp.p.substeps > 1) {
+        switch (h->dp.p.model_kind) {
+            case AC_MODEL_LINEAR: hipLaunchKernelGGL((k_step_sens<AC_MODEL_LINEAR, true>), grid_an, kBlock, 0, st, h->dp, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c); break;
+            case AC_MODEL_POLY: hipLaunchKernelGGL((k_step_sens<AC_MODEL_POLY, true>), grid_an, kBlock, 0, st, h->dp, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c); break;
+            case AC_MODEL_QUAD: hipLaunchKernelGGL((k_step_sens<AC_MODEL_QUAD, true>), grid_an, kBlock, 0, st, h->dp, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c); break;
+            default: hipLaunchKernelGGL((k_step_sens<AC_MODEL_DEFAULT, true>), grid_an, kBlock, 0, st, h->dp, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c); break;
+        }
+    } else {
+        switch (h->dp.p.model_kind) {
+            case AC_MODEL_LINEAR: hipLaunchKernelGGL((k_step_sens<AC_MODEL_LINEAR, false>), grid_an, kBlock, 0, st, h->dp, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c); break;
+            case AC_MODEL_POLY: hipLaunchKernelGGL((k_step_sens<AC_MODEL_POLY, false>), grid_an, kBlock, 0, st, h->dp, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c); break;
+            case AC_MODEL_QUAD: hipLaunchKernelGGL((k_step_sens<AC_MODEL_QUAD, false>), grid_an, kBlock, 0, st, h->dp, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c); break;
+            default: hipLaunchKernelGGL((k_step_sens<AC_MODEL_DEFAULT, false>), grid_an, kBlock, 0, st, h->dp, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c); break;
+        }
+    }
     note_launch(h, "k_step_sens", grid_an, kBlock, 0);
     AC_HIP(hipGetLastError());
     return AC_OK;

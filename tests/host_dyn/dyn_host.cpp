@@ -78,8 +78,13 @@ extern "C" int host_dyn_sens(const ac_params* p, const float* linear_W, const fl
     DevParams P{};
     P.p = *p;
     if (linear_W) for (int i = 0; i < 36; ++i) P.linear_W[i] = linear_W[i];
-    if (poly_coef) { for (int i = 0; i < 6 * 34; ++i) P.poly_coef[i] = poly_coef[i]; poly_gradient_tables(P.poly_coef, P.poly_grad); }
-    if (poly_intercept) for (int i = 0; i < 6; ++i) P.poly_intercept[i] = poly_intercept[i];
+    alignas(64) static thread_local float tab[kPolyTabFloats];
+    if (poly_coef && poly_intercept) {
+        float grad[6 * 4 * 15];
+        poly_gradient_tables(poly_coef, grad);
+        poly_pack_tables(poly_coef, poly_intercept, grad, tab);
+        P.poly_tab = tab;
+    }
     if (what == 0 && P.p.substeps > 1) return -1;
 #define AC_CASE(M_, N_) if (P.p.model_kind == M_ && N == N_) { run<M_, N_>(P, what, X, U, dt, n, Xn, A, B, c); return 0; }
     AC_CASE(AC_MODEL_DEFAULT, 2) AC_CASE(AC_MODEL_DEFAULT, 4) AC_CASE(AC_MODEL_DEFAULT, 8)
