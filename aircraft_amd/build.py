@@ -19,7 +19,8 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
 # register-spill scratch from 228 to 36 B/lane (HBM traffic 1.9x -> 1.1x of the algorithmic bytes) at +0.6 % speed
 # (same-box A/Bs).  Results are bit-identical: neither changes the order of any accumulation.
 UNIT_FLAGS = {
-    "an_inst_sens": ["-fno-slp-vectorize"],
+    "an_inst_sens_poly": ["-fno-slp-vectorize"],
+    "nn_inst_wt2_mfma_sens_w2": ["-fno-slp-vectorize"],  # (the same, for the small-net kernel at two waves per SIMD)
     "nn_inst_wt8_mfma_sens": ["-DAC_CH=2", "-mllvm", "-slp-threshold=6"],
     "nn_inst_wt8_mfma_pair": ["-DAC_CH=2", "-mllvm", "-slp-threshold=6"],
 }

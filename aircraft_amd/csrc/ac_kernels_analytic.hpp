@@ -600,23 +600,27 @@ __global__ __launch_bounds__(kBlock, kSensWavesPerSimd) void k_step_sens(const D
     SensIOT<kAnN, MODEL == AC_MODEL_QUAD>::store(g, uo, x, A, Bm, c, true);
 }
 
-// The step + sensitivity and derivative + sensitivity kernels of the analytic models are compiled in a translation unit of
-// their own (an_inst_sens.hip, built with -fno-slp-vectorize: packing pairs of tangent chains into v_pk_fma_f32 costs the
-// two-waves-per-SIMD kernels more registers than they have — 300 B/lane of scratch for the cubic fits — and buys nothing
-// at that occupancy); every other unit only refers to them.
+// The step + sensitivity and derivative + sensitivity kernels of the analytic models are compiled in translation units of
+// their own; every other unit only refers to them.  an_inst_sens_poly.hip is built with -fno-slp-vectorize: packing pairs
+// of tangent chains into v_pk_fma_f32 costs the cubic-fit kernel more registers than two waves per SIMD leave it (300 B/lane
+// of scratch); an_inst_sens.hip (default / linear / quadrotor) keeps the packing — those kernels fit either way, and at two
+// waves per SIMD a packed instruction takes one issue slot like any other (profiles/r04_analytic_pmc_*.json).
 #define AC_AN_SENS_ARGS const DevParams, const float*, const float*, float, const float*, long, long, float*, float*, float*, float*
 #define AC_AN_DERIV_ARGS const DevParams, const float*, const float*, long, long, float*, float*, float*
-#ifdef AC_AN_SENS_INSTANTIATE
-#define AC_AN_EXTERN
+#define AC_AN_MODEL(EXT, M)                                              \
+    EXT template __global__ void k_step_sens<M, false>(AC_AN_SENS_ARGS); \
+    EXT template __global__ void k_step_sens<M, true>(AC_AN_SENS_ARGS);  \
+    EXT template __global__ void k_deriv_sens<M>(AC_AN_DERIV_ARGS);
+#if defined(AC_AN_SENS_INSTANTIATE) && AC_AN_SENS_INSTANTIATE == 1
+AC_AN_MODEL(, AC_MODEL_DEFAULT) AC_AN_MODEL(, AC_MODEL_LINEAR) AC_AN_MODEL(, AC_MODEL_QUAD)
 #else
-#define AC_AN_EXTERN extern
+AC_AN_MODEL(extern, AC_MODEL_DEFAULT) AC_AN_MODEL(extern, AC_MODEL_LINEAR) AC_AN_MODEL(extern, AC_MODEL_QUAD)
 #endif
-#define AC_AN_MODEL(M)                                                            \
-    AC_AN_EXTERN template __global__ void k_step_sens<M, false>(AC_AN_SENS_ARGS); \
-    AC_AN_EXTERN template __global__ void k_step_sens<M, true>(AC_AN_SENS_ARGS);  \
-    AC_AN_EXTERN template __global__ void k_deriv_sens<M>(AC_AN_DERIV_ARGS);
-AC_AN_MODEL(AC_MODEL_DEFAULT) AC_AN_MODEL(AC_MODEL_LINEAR) AC_AN_MODEL(AC_MODEL_POLY) AC_AN_MODEL(AC_MODEL_QUAD)
+#if defined(AC_AN_SENS_INSTANTIATE) && AC_AN_SENS_INSTANTIATE == 2
+AC_AN_MODEL(, AC_MODEL_POLY)
+#else
+AC_AN_MODEL(extern, AC_MODEL_POLY)
+#endif
 #undef AC_AN_MODEL
-#undef AC_AN_EXTERN
 
 }  // namespace ac

@@ -90,6 +90,51 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_step_sens(const DevParams P, c
 #endif
 }
 
+// The same for SMALL nets (WT = 2: hidden widths <= 32, e.g. the reference's own 5-16-32-6 checkpoint) at TWO waves per
+// SIMD.  With so little matrix work the step is bound by vector-ALU issue of the dual rigid-body arithmetic
+// (profiles/r04_analytic_pmc_before.json, "real": 80 % of the wave cycles in VALU instructions at one wave per SIMD, where
+// a wave issues one every 4 cycles), so the lever is a second wave on every SIMD: fused per-direction tangents and the RK4
+// sum in LDS bring the kernel under 256 registers, and the grid is two persistent workgroups per CU.
+template <int WT>
+__global__ __launch_bounds__(kBlock, 2) void k_nn_step_sens_w2(const DevParams P, const MlpPlan plan,
+                                                               const float* __restrict__ blob,
+                                                               const float* __restrict__ X, const float* __restrict__ U,
+                                                               float dt, const float* __restrict__ dt_per_unit, long n, long blk,
+                                                               float* __restrict__ Xn, float* __restrict__ A,
+                                                               float* __restrict__ Bm, float* __restrict__ c) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef MlpEngine<6, WT, true> Engine;
+    Engine eng(plan, blob, smem);
+    eng.load_weights();
+    MlpCoeffs<Engine, true> coeffs(eng);
+    float4* acc_words = reinterpret_cast<float4*>(smem + ((plan.lds_total + 15) & ~15));
+    const long ntasks = (n + 63) / 64;
+#pragma nounroll
+    for (long task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const WaveUnit w(tid, task, n, blk);
+        float xv[13], uv[7];
+        load_rows<13>(X, w.ua, xv);
+        load_rows<7>(U, w.ua, uv);
+        const float hv = dt_per_unit ? dt_per_unit[w.unit] : dt;
+        Dual<4> x[13];
+        LdsAcc4 acc(&acc_words[tid], kBlock);
+        sens_update<4, 1>(P, coeffs, w.g, w.col, w.ua, xv, uv, hv, x, A, Bm, c, w.live, acc);
+        if (w.live) {
+            const UnitAddr uo = w.ua.late();
+            if (w.g == 0) {
+                float* p = Xn + uo.off(13);
+#pragma unroll
+                for (int i = 0; i < 13; ++i) p[(long)i * blk] = x[i].v;
+            }
+            SensIO::store(w.g, uo, x, A, Bm, c, true);
+        }
+    }
+    eng.drain();
+}
+constexpr int kSensW2AccBytes = 13 * kBlock * 16;
+
 // x_dot = f(x, u) with Fx = df/dx, Fu = df/du through the surrogate: ONE evaluation of the 6-slab engine (value + five
 // input tangents) and the dual rigid-body arithmetic on the same lanes — the first stage of k_nn_step_sens on its own.
 template <int WT, bool USE_MFMA>

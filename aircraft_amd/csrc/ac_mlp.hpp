@@ -1213,12 +1213,37 @@ struct MlpEngineCoopReg {
 // primal aerodynamic inputs of the stage state and keeps only y[6] (+ J[6][5]); operator() then applies the
 // output scaler and, for duals, the chain rule  dC = J . d(inputs)  — the custom-Jacobian rule l4casadi
 // supplies to CasADi in the reference (coefficient_models.py:93-100).
-template <class Engine> struct MlpCoeffs {
+// FUSED = true additionally offers linearise() / tangent() — the per-direction protocol of state_derivative for duals
+// (ac_dynamics.hpp), which needs no N-wide intermediates: the kernels that run two waves per SIMD take it.
+template <class Engine, bool FUSED = false> struct MlpCoeffs {
     static constexpr int kModel = AC_MODEL_NN;
+    static constexpr bool kFusedTangent = FUSED && Engine::kTangent;
     Engine& eng;
     float y[6];
     float J[Engine::kTangent ? 6 : 1][5];
     AC_DI explicit MlpCoeffs(Engine& e) : eng(e) {}
+
+    AC_DI void linearise(const DevParams& P, const AeroPre<float>& a, const float x[13], const float u[7], float C[6]) {
+        (*this)(P, a, x, u, C);
+        if constexpr (Engine::kTangent) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) J[k][j] = J[k][j] * P.mlp_jscale[k][j];  // (consumed by tangent() only, once per stage)
+        }
+    }
+    AC_DI void tangent(const DevParams& P, const AeroD& d, float dC[6]) const {
+        (void)P;
+        const float in[5] = {d.qbar, d.alpha, d.beta, d.da, d.de};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) s = fmaf(J[k][j], in[j], s);
+            dC[k] = s;
+        }
+        dC[5] = fmaf(-0.1f * 6.0f * kDeg, d.dr, dC[5]);
+    }
 
     template <class T> AC_DI void prefetch(const DevParams& P, const T x[13], const float uv[7]) {
         float xf[13];

@@ -872,6 +872,20 @@ static int sens_impl(ac_handle* h, const float* X, const float* U, float dt, con
             if (rem > 0 && rem <= 32 * cus) { n_main = n - rem; n_pair = rem; }
             if (h->all_pair) { n_main = 0; n_pair = n; }
         }
+        if (h->use_mfma && h->wt == 2 && h->dp.p.substeps <= 1) {
+            // small nets: two persistent workgroups per CU = two waves per SIMD (k_nn_step_sens_w2)
+            const int lds = ((h->plan_sens.lds_total + 15) & ~15) + kSensW2AccBytes;
+            if (lds <= 80 * 1024) {
+                const int grid = (int)std::min<long>((n + 63) / 64, 2 * cus);
+                auto kern = k_nn_step_sens_w2<2>;
+                int rc_ = set_lds_limit(h, kern, lds);
+                if (rc_ != AC_OK) return rc_;
+                hipLaunchKernelGGL(kern, grid, kBlock, lds, st, h->dp, h->plan_sens, h->d_blob, X, U, dt, dt_per_unit, n, blk, Xn, A, Bm, c);
+                note_launch(h, "k_nn_step_sens_w2", grid, kBlock, lds);
+                AC_HIP(hipGetLastError());
+                return AC_OK;
+            }
+        }
         if (n_main > 0) {
             // persistent: at most one workgroup per CU, each walks the 64-unit tasks b, b + grid, ... (k_nn_step_sens)
 #ifndef AC_NO_PERSIST

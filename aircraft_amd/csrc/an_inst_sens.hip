@@ -1,5 +1,4 @@
-// Step + sensitivity and derivative + sensitivity kernels of the analytic coefficient models (default / linear / poly /
-// quadrotor): explicit instantiations, built with -fno-slp-vectorize (aircraft_amd/build.py UNIT_FLAGS; the reason is next
-// to the declarations in ac_kernels_analytic.hpp).
+// Step + sensitivity and derivative + sensitivity kernels of the default / linear / quadrotor force models: explicit
+// instantiations (see the declarations at the end of ac_kernels_analytic.hpp).
 #define AC_AN_SENS_INSTANTIATE 1
 #include "ac_kernels_analytic.hpp"
