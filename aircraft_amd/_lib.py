@@ -44,6 +44,13 @@ class IlqrCost(C.Structure):
                 ("u_lin", C.c_float * 7), ("dt_row", C.c_int)]
 
 
+class GoalLoss(C.Structure):
+    """struct ac_goal_loss (include/aircraft_hip.h); defaults are Controller.loss, main/control/control.py:44-68."""
+    _fields_ = [("w_goal", C.c_float), ("w_rate", C.c_float), ("eps_rate", C.c_float), ("w_height", C.c_float),
+                ("w_speed", C.c_float), ("w_vx", C.c_float), ("w_vyz", C.c_float), ("vx_max", C.c_float), ("w_al", C.c_float),
+                ("time_row", C.c_int)]
+
+
 class EnvelopePenalty(C.Structure):
     """struct ac_envelope_penalty (include/aircraft_hip.h)."""
     _fields_ = [("lo", C.c_float * 4), ("hi", C.c_float * 4), ("weight", C.c_float)]
@@ -76,6 +83,9 @@ PROTOTYPES = {
     "ac_state_derivative_sens_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, _VP, _VP, _VP, _VP]),
     "ac_shoot_derivative_sens_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP]),
     "ac_shoot_derivative_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
+    "ac_shoot_defect_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, C.c_long, _VP, _VP]),
+    "ac_shoot_implicit_defect_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, C.c_long, _VP, _VP]),
+    "ac_shoot_implicit_rows_f32": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP, _VP]),
     "ac_envelope_f32": (C.c_int, [_VP, _VP, C.c_long, _VP, _VP, _VP]),
     "ac_shoot_envelope_f32": (C.c_int, [_VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP]),
     "ac_envelope_cost_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
@@ -100,6 +110,11 @@ PROTOTYPES = {
     "ac_ilqr_backward_newton_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP,
                                               _VP, _VP, _VP]),
     "ac_ilqr_cost_node_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_long, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
+    "ac_goal_cost_f32": (C.c_int, [_VP, _VP, _VP, _VP, C.c_long, _VP, _VP, C.c_long, C.c_long, _VP, _VP]),
+    "ac_goal_model_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "ac_goal_multiplier_f32": (C.c_int, [_VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP, _VP]),
+    "ac_ilqr_backward_goal_f32": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_long, C.c_long, _VP, _VP,
+                                            _VP, _VP]),
     "ac_set_track": (C.c_int, [_VP, C.c_int, _FP, C.c_float]),
     "ac_track_eval_f32": (C.c_int, [_VP, _VP, C.c_long, _VP, _VP, _VP]),
     "ac_track_progress_f32": (C.c_int, [_VP, _VP, _VP, _VP, C.c_float, C.c_long, C.c_long, C.c_int, _VP, _VP, _VP, _VP,

@@ -1,5 +1,5 @@
 from .base import MultipleShooting
-from .ilqr import ILQR, QuadraticCost
+from .ilqr import ILQR, GoalAcquisition, QuadraticCost
 from .moving_horizon import MHTT, MHTTWeights, RecedingHorizon
 from .track import Track
 

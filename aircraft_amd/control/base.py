@@ -112,21 +112,19 @@ class MultipleShooting:
             'implicit'  r_k = x_{k+1} - (x_k + dt_k f(x_{k+1}, u_k))           (:282-284)
         `integration` defaults to opts['integration'] (default 'explicit', as in the reference)."""
         mode = integration or self.opts.get("integration", "explicit")
-        H = U.shape[0]
-        if mode == "explicit":
-            return X[1 : H + 1] - self.propagate(X, U, dt)
-        if mode != "implicit":
+        if mode not in ("explicit", "implicit"):
             raise NotImplementedError("Must choose integration mode from ['implicit', 'explicit']")  # base.py:286
-        f = self.derivative(X[1 : H + 1], U)  # the residual needs f alone: the forward kernel, no Jacobian blocks
-        return X[1 : H + 1] - X[:H] - self._dt_tensor(dt, X) * f
-
-    def _dt_tensor(self, dt, X):
         torch = _torch()
-        if dt is None:
-            dt = self.dt
-        if isinstance(dt, torch.Tensor) and dt.numel() > 1:
-            return dt.to(device=X.device, dtype=torch.float32)[:, None, :]
-        return float(dt)
+        lib = self.system._sync()
+        H, B, dts, dtp, keep = self._shoot_args(X, U, dt)
+        assert X.shape[0] == H + 1, "the defect rows pair every node with the next: X must hold N + 1 nodes"
+        out = torch.empty((H, self.state_dim, B), device=X.device, dtype=torch.float32)
+        fn = lib.ac_shoot_defect_f32 if mode == "explicit" else lib.ac_shoot_implicit_defect_f32
+        # one launch: the step (explicit) or derivative (implicit) kernel stores the row in place of its result
+        _lib.check(fn(self.system._handle, X.data_ptr(), U.data_ptr(), dts, dtp, B, H, out.data_ptr(), self.system._stream()),
+                   fn.__name__)
+        del keep
+        return out
 
     def derivative(self, Xn, Un, out=None):
         """f(x, u) at the H (state, control) pairs Xn (H, 13, B) [a view such as X[1:] is used in place], Un (H, 7, B)."""
@@ -162,16 +160,22 @@ class MultipleShooting:
     def linearise_implicit(self, X, U, dt=None):
         """Jacobian blocks of the implicit defect rows r_k = x_{k+1} - x_k - dt_k f(x_{k+1}, u_k):
             d r_k / d x_k = -I,   d r_k / d x_{k+1} = I - dt_k Fx,   d r_k / d u_k = -dt_k Fu,   d r_k / d dt_k = -f
-        Returns (r, Jnext (N,13,13,B), Ju (N,13,7,B), jdt (N,13,B)); Fx, Fu, f come from ONE launch of the derivative-
-        sensitivity kernel on the next nodes, the scaling below is elementwise."""
+        Returns (r, Jnext (N,13,13,B), Ju (N,13,7,B), jdt (N,13,B)), all four written by ONE launch of the derivative-
+        sensitivity kernel on the next nodes (ac_shoot_implicit_rows_f32)."""
         torch = _torch()
-        H = U.shape[0]
-        f, Fx, Fu = self.derivative_sens(X[1 : H + 1], U)
-        dtt = self._dt_tensor(dt, X)
-        r = X[1 : H + 1] - X[:H] - dtt * f
-        d4 = dtt[:, None] if isinstance(dtt, torch.Tensor) else dtt
-        eye = torch.eye(self.state_dim, device=X.device)[None, :, :, None]
-        return r, eye - d4 * Fx, -(d4 * Fu), -f
+        lib = self.system._sync()
+        H, B, dts, dtp, keep = self._shoot_args(X, U, dt)
+        assert X.shape[0] == H + 1
+        ns, nc = self.state_dim, _lib.NUM_CONTROLS
+        r = torch.empty((H, ns, B), device=X.device)
+        Jn = torch.empty((H, ns, ns, B), device=X.device)
+        Ju = torch.empty((H, ns, nc, B), device=X.device)
+        jdt = torch.empty((H, ns, B), device=X.device)
+        _lib.check(lib.ac_shoot_implicit_rows_f32(self.system._handle, X.data_ptr(), U.data_ptr(), dts, dtp, B, H, r.data_ptr(),
+                                                  Jn.data_ptr(), Ju.data_ptr(), jdt.data_ptr(), self.system._stream()),
+                   "ac_shoot_implicit_rows_f32")
+        del keep
+        return r, Jn, Ju, jdt
 
     def quaternion_rows(self, Xn, Un=None, mode: Optional[str] = None):
         """Quaternion rows of ControlProblem.state_constraint on the nodes Xn (H, 13, B) (the NEXT nodes x_{k+1}):

@@ -237,9 +237,12 @@ class ILQR(MultipleShooting):
                    "ac_ilqr_costate_f32")
         return out
 
-    def backward(self, X, U, A, Bm, out=None, Hz=None, node="auto"):
+    _goal_model = None  # GoalAcquisition sets it (see iterate)
+
+    def backward(self, X, U, A, Bm, out=None, Hz=None, node="auto", uglin=None):
         """Riccati pass -> K (N, 7, 13, B), kff (N, 7, B), dV (2, B).  Hz (N, 21, 21, B): optional second-order
-        dynamics blocks from `hessian()` (exact-Hessian / Newton step)."""
+        dynamics blocks from `hessian()` (exact-Hessian / Newton step).  uglin (N, 7, B): optional per-node control
+        gradient (needs node arrays and Hz: ac_ilqr_backward_goal_f32)."""
         torch = _torch()
         lib = self.system._sync()
         H, B = U.shape[0], U.shape[2]
@@ -249,6 +252,14 @@ class ILQR(MultipleShooting):
             out = (torch.empty((H, 7, 13, B), device=X.device), torch.empty((H, 7, B), device=X.device),
                    torch.empty((2, B), device=X.device))
         K, kff, dV = out
+        if uglin is not None:
+            assert node is not None and Hz is not None
+            _lib.check(lib.ac_ilqr_backward_goal_f32(self.system._handle, self._cstruct(), *self._ptrs(node),
+                                                     C.c_void_p(uglin.data_ptr()), C.c_void_p(Hz.data_ptr()), X.data_ptr(),
+                                                     U.data_ptr(), A.data_ptr(), Bm.data_ptr(), B, H, K.data_ptr(),
+                                                     kff.data_ptr(), dV.data_ptr(), self.system._stream()),
+                       "ac_ilqr_backward_goal_f32")
+            return K, kff, dV
         _lib.check(lib.ac_ilqr_backward_newton_f32(self.system._handle, self._cstruct(), *self._ptrs(node),
                                                    C.c_void_p(Hz.data_ptr() if Hz is not None else 0), X.data_ptr(),
                                                    U.data_ptr(), A.data_ptr(), Bm.data_ptr(), B, H, K.data_ptr(),
@@ -289,6 +300,11 @@ class ILQR(MultipleShooting):
         node = self._node_cost(X, U)  # None, or a subclass's per-node arrays (rewritten by it every iteration)
         Hz = None
         env = self.envelope_weight > 0
+        goal = self._goal_model is not None  # GoalAcquisition: node arrays + control gradient + (u, u) curvature
+        if self.hessian_mode != "exact" and (env or goal):
+            Hz = ws["Hz"].zero_()
+        # (first: it WRITES the node arrays the envelope below adds to; adds the rate curvature to Hz, returns the control gradient)
+        uglin = self._goal_model(X, U, Hz) if goal else None
         if env:
             if node is None:  # the constant cost as per-node arrays, so that the penalty gradient has a place to go
                 ws["env_glin"].zero_()
@@ -297,11 +313,9 @@ class ILQR(MultipleShooting):
         if self.hessian_mode == "exact":
             self.costate(X, ws["A"], node, out=ws["Lam"])
             Hz = self.hessian(X, U, ws["Lam"], out=ws["Hz"])
-        elif env:
-            Hz = ws["Hz"].zero_()
         if env:
             self._envelope_model(X, Hz=Hz)
-        self.backward(X, U, ws["A"], ws["Bm"], out=(ws["K"], ws["kff"], ws["dV"]), Hz=Hz, node=node)
+        self.backward(X, U, ws["A"], ws["Bm"], out=(ws["K"], ws["kff"], ws["dV"]), Hz=Hz, node=node, uglin=uglin)
         self.forward(x0, X, U, ws["K"], ws["kff"], out=(ws["Xc"], ws["Uc"]))
         self.trajectory_cost(ws["Xc"], ws["Uc"], out=ws["Jc"])
         self.trajectory_cost(X, U, out=ws["J0"])
@@ -348,3 +362,100 @@ class ILQR(MultipleShooting):
             if save_to:
                 self.save_progress(save_to, it + 1, X, U, save_instance)
         return X, U, torch.stack(hist)
+
+
+class GoalAcquisition(ILQR):
+    """The reference's goal-acquisition problem (Controller, main/control/control.py:25-70) on the batched sweep: reach
+    goal (x, y) at the final node while the loss of Controller.loss is minimised —
+
+        1000 |p_xy(N) - goal|^2 + 100 sum l0_smooth(u_{k+1} - u_k, 1e-2) + (z_N - z_0)^2 - sum v_rel.v_rel / 100 / N
+        + vel_param 1000 v_x(N) + 1000 (v_y(N)^2 + v_z(N)^2) [+ 10000 T],     subject to  v_x(N) < -2
+
+    — for B instances at once (independent goals / initial states / random restarts).  The EXACT loss drives the line
+    search and the history (ac_goal_cost_f32); the backward pass sees its convex quadratic model (ac_goal_model_f32:
+    csrc/ac_goal.hpp states what is modelled how); the terminal inequality is an augmented-Lagrangian term with one
+    multiplier per instance, updated by `update_goal_multiplier()` (`solve(al_every=)`).  time='variable' adds the
+    reference's time term 10000 T through w_time (opts['time'] = 'progress' in the reference's driver, control.py:182)."""
+
+    def __init__(self, *, system, goal, dt: float = 0.01, num_nodes: int = 400, vel_param: float = 1.0, w_goal: float = 1000.0,
+                 w_rate: float = 100.0, eps_rate: float = 1e-2, w_height: float = 1.0, w_speed: float = 0.01,
+                 w_final_velocity: float = 1000.0, vx_max: float = -2.0, w_al: float = 10.0, r: float = 0.0, reg: float = 1e-2,
+                 time: str = "fixed", w_time: float = 10000.0, **kw):
+        cost = QuadraticCost(q=[0.0] * 13, qf=[0.0] * 13, r=[float(r)] * 7, reg=float(reg))  # every state term lives in the node arrays
+        super().__init__(system=system, dt=dt, num_nodes=num_nodes, cost=cost, time=time, w_time=w_time if time == "variable" else 0.0,
+                         **kw)
+        assert self.hessian_mode == "gauss-newton"
+        self.goal = goal
+        self.loss = _lib.GoalLoss()
+        ls = self.loss
+        ls.w_goal, ls.w_rate, ls.eps_rate, ls.w_height, ls.w_speed = w_goal, w_rate, eps_rate, w_height, w_speed
+        ls.w_vx, ls.w_vyz, ls.vx_max, ls.w_al, ls.time_row = vel_param * w_final_velocity, w_final_velocity, vx_max, w_al, self.time_row
+        self._gws = None
+
+    def _goal_ws(self, B, dev):
+        torch = _torch()
+        H = self.num_nodes
+        if self._gws is None or self._gws["key"] != (B, H, str(dev)):
+            f = lambda *s: torch.zeros(s, device=dev, dtype=torch.float32)  # noqa: E731
+            g = torch.as_tensor(self.goal, dtype=torch.float32, device=dev).reshape(2, -1)
+            if g.shape[1] == 1:
+                g = g.expand(2, B)
+            assert g.shape == (2, B), "goal: (2,) for every instance or (2, B)"
+            self._gws = dict(key=(B, H, str(dev)), goal=g.contiguous(), lam=f(B), viol=f(B), nq=f(H + 1, 13, B),
+                             nx=f(H + 1, 13, B), ng=f(H + 1, 13, B), ug=f(H, 7, B))
+            ws = self._workspace(B, dev)
+            if "Hz" not in ws:
+                ws["Hz"] = f(H, 21, 21, B)
+        return self._gws
+
+    # the node arrays are produced together with the control gradient (one launch) in _goal_model; _node_cost hands them over
+    def _node_cost(self, X, U):
+        g = self._goal_ws(U.shape[2], U.device)
+        return (g["nq"], g["nx"], g["ng"])
+
+    def _goal_model(self, X, U, Hz):
+        lib = self.system._sync()
+        H, B = U.shape[0], U.shape[2]
+        g = self._goal_ws(B, U.device)
+        _lib.check(lib.ac_goal_model_f32(self.system._handle, C.byref(self.loss), g["goal"].data_ptr(), g["lam"].data_ptr(),
+                                         X.data_ptr(), U.data_ptr(), B, H, g["nq"].data_ptr(), g["nx"].data_ptr(),
+                                         g["ng"].data_ptr(), g["ug"].data_ptr(), Hz.data_ptr(), self.system._stream()),
+                   "ac_goal_model_f32")
+        return g["ug"]
+
+    def trajectory_cost(self, X, U, out=None):
+        """The exact loss of every column of (X, U) (a candidate batch reads instance b % B's goal and multiplier)."""
+        lib = self.system._sync()
+        out = super().trajectory_cost(X, U, out=out)  # control terms of the cost struct (actuation, time)
+        Bc, H = U.shape[2], U.shape[0]
+        Bn = self._gws["key"][0] if self._gws is not None else Bc
+        g = self._goal_ws(Bn, U.device)
+        _lib.check(lib.ac_goal_cost_f32(self.system._handle, C.byref(self.loss), g["goal"].data_ptr(), g["lam"].data_ptr(), Bn,
+                                        X.data_ptr(), U.data_ptr(), Bc, H, out.data_ptr(), self.system._stream()),
+                   "ac_goal_cost_f32")
+        return out
+
+    def update_goal_multiplier(self, X):
+        """First-order update of the terminal inequality's multipliers at the iterate; returns max(0, v_x(N) - vx_max) (B,)."""
+        lib = self.system._sync()
+        H, B = X.shape[0] - 1, X.shape[2]
+        g = self._goal_ws(B, X.device)
+        _lib.check(lib.ac_goal_multiplier_f32(self.system._handle, C.byref(self.loss), X.data_ptr(), B, H, g["lam"].data_ptr(),
+                                              g["viol"].data_ptr(), self.system._stream()), "ac_goal_multiplier_f32")
+        return g["viol"]
+
+    def solve(self, x0, U0, iters: int = 10, al_every: int = 0, **kw):
+        torch = _torch()
+        self._goal_ws(U0.shape[2], U0.device)
+        if not al_every:
+            return super().solve(x0, U0, iters=iters, **kw)
+        # multiplier updates between blocks of sweeps (the objective changes with them: monotone within a block)
+        X, U, hist = super().solve(x0, U0, iters=min(al_every, iters), **kw)
+        hists, done = [hist], min(al_every, iters)
+        while done < iters:
+            self.update_goal_multiplier(X)
+            n = min(al_every, iters - done)
+            X, U, h = super().solve(x0, U, iters=n, **kw)
+            hists.append(h)
+            done += n
+        return X, U, torch.cat(hists)

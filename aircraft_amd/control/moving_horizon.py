@@ -69,6 +69,11 @@ class RecedingHorizon:
         warm_start: 'shift' re-uses the tail of the previous controls, 'zero' restarts from zero controls as the
         reference's MHTT.initialise does (control/moving_horizon.py:204)."""
         assert 0 <= overlap < solver.num_nodes and iterations >= 0
+        if getattr(solver, "time_row", 0) != 0:
+            # The loop re-rolls the trajectory at the fixed solver.dt and shifts / zeroes whole control columns; a solver
+            # that carries dt_k in a control row would be linearised at dt_k = 0 after a 'zero' warm start and scored
+            # against a rollout that is not its own (MHTT makes the same restriction: time == 'fixed').
+            raise ValueError("RecedingHorizon needs a fixed-time solver: ILQR(time='fixed')")
         self.solver, self.overlap, self.iterations, self.warm_start = solver, overlap, iterations, warm_start
         self.keep = solver.num_nodes - overlap
         self._graph = None

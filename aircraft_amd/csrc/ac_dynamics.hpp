@@ -33,6 +33,13 @@ struct DevParams {
     // PolyTab reads them behind a pointer the optimiser cannot see through, taken anew wherever a fit is evaluated, and
     // the evaluations stream the rows two at a time (the next pair in flight while the current one is consumed).
     const float* poly_tab;
+    // What the forward / derivative kernels store in place of their result: the multiple-shooting rows built from it
+    // (ControlProblem.state_constraint, control/base.py:275-286).  Set by the ac_shoot_defect / ac_shoot_implicit_* entry
+    // points on the copy of this struct that a launch takes; AC_ROWS_PLAIN everywhere else.
+    int rows;                       // AC_ROWS_*
+    float rows_dt;                  // dt_k of the implicit rows (the derivative kernels have no dt argument)
+    const float* rows_dt_per_unit;  // [n] or NULL
+    float* rows_aux;                // implicit rows with Jacobians: d r / d dt = -f, [13][n]
     float mlp_in_mean[5], mlp_in_std[5], mlp_out_mean[6], mlp_out_std[6];
     // mlp_out_std[k] / mlp_in_std[j], rounded once on the host (IEEE single division, what the device computes too): the
     // chain rule dC_k = sum_j J[k][j] * jscale[k][j] * d(in_j) reads them as scalar operands instead of holding thirty
@@ -41,6 +48,7 @@ struct DevParams {
 };
 
 constexpr float kDeg = 0.017453292519943295f;  // pi/180
+enum { AC_ROWS_PLAIN = 0, AC_ROWS_DEFECT = 1, AC_ROWS_IMPLICIT = 2 };
 
 constexpr int kPolyTabRows = 42, kPolyTabFloats = kPolyTabRows * 16;
 struct Row16 { float c[16]; };

@@ -33,6 +33,10 @@ struct NodeCost {
     const float* __restrict__ xref;
     const float* __restrict__ glin;
     long Bn;
+    // optional per-node, per-instance CONTROL gradient [H][7][Bn] added to Q_u (the backward pass with second-order blocks
+    // only: k_ilqr_backward<true, true>): the control-rate term of the goal-acquisition loss (ac_goal.hpp), whose curvature
+    // arrives in the (u, u) block of Hz
+    const float* __restrict__ uglin = nullptr;
     AC_DI bool on() const { return q != nullptr; }
     // value and gradient pieces of row j at node k
     // NODE is a compile-time switch of the kernels (constant cost = the original straight-line code); bn = b % Bn
@@ -67,8 +71,9 @@ struct AlphaSet {
 constexpr int kIlqrWork = 736;  // LDS floats of the per-instance work area (layout below)
 
 template <bool NODE, bool NEWTON> struct IlqrRing {
-    static constexpr int kInstr = 6 + (NEWTON ? 7 : 0);          // LDS-DMA wave-instructions per node
-    static constexpr int kNodeFloats = NEWTON ? 768 : 320;      // A 0..168, B 169..259, x 260, u 273, q 280, xref 293, glin 306, Hz 320..760
+    static constexpr bool kUglin = NODE && NEWTON;               // the control-gradient row (NodeCost::uglin) travels in the ring
+    static constexpr int kInstr = 6 + (NEWTON ? 7 : 0) + (kUglin ? 1 : 0);  // LDS-DMA wave-instructions per node
+    static constexpr int kNodeFloats = NEWTON ? 768 : 320;      // A 0..168, B 169..259, x 260, u 273, q 280, xref 293, glin 306, Hz 320..760, uglin 761..767
     static constexpr int kDepth = NEWTON ? 5 : 8;                // nodes in flight (kInstr * (kDepth - 1) <= 63)
     static_assert(kInstr * (kDepth - 1) <= 63, "vmcnt is a 6-bit counter");
 };
@@ -128,7 +133,12 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const No
             for (int c = 0; c < 7; ++c)
                 if (c * 64 + t < 441) ilqr_glds(hz + (long)(c * 64 + t) * B, dst + 320 + c * 64);
         }
+        if constexpr (R::kUglin) {  // (always issued, so that the vmcnt bookkeeping is static; without the array: u_k again, unused)
+            const float* ug = N.uglin ? N.uglin + (k * 7) * B + b : U + (k * 7) * B + b;
+            if (t < 7) ilqr_glds(ug + (long)t * B, dst + 761);
+        }
     };
+    const float ug_on = (R::kUglin && N.uglin) ? 1.f : 0.f;
 
     // terminal condition (ordinary loads, before any LDS-DMA is in flight)
     float qterm = 0.f;
@@ -163,7 +173,11 @@ __global__ __launch_bounds__(64) void k_ilqr_backward(const IlqrCost C, const No
             if constexpr (NODE) { qjj = nd[280 + j]; xr = nd[293 + j]; gl = nd[306 + j]; }
             if (rb == 0) sqx[j] = fmaf(qjj, nd[260 + j] - xr, gl);
         }
-        if (j < 7 && rb == 0) squ[j] = fmaf(C.r[j], nd[273 + j], C.u_lin[j]);
+        if (j < 7 && rb == 0) {
+            float g = fmaf(C.r[j], nd[273 + j], C.u_lin[j]);
+            if constexpr (R::kUglin) g = fmaf(ug_on, nd[761 + j], g);
+            squ[j] = g;
+        }
         ilqr_sync();
         // This lane's columns of A_k and B_k stay in registers for the node (read once from the ring slot).
         float acol[13], bcol[13];

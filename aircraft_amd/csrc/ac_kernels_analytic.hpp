@@ -38,6 +38,34 @@ template <int ROWS> AC_DI void store_rows(float* __restrict__ dst, const UnitAdd
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) p[(long)r * ua.blk] = v[r];
 }
+// What a forward (x+ = F) or derivative (x_dot = f) kernel stores for unit `unit` of the node-major buffer X: its result
+// v, or the defect row built from it (control/base.py:275-286) — the neighbouring node of the same instance is one block
+// of X away, so the rows need no pointer of their own:
+//   AC_ROWS_DEFECT    x_{k+1} - F(x_k, u_k, dt_k)                      X = nodes 0 .. H, unit (k, b) reads node k + 1
+//   AC_ROWS_IMPLICIT  x_{k+1} - x_k - dt_k f(x_{k+1}, u_k)            X = nodes 1 .. H (the caller's X + 13 B), reads node k
+AC_DI void store_state_rows(const DevParams& P, const float* __restrict__ X, float* __restrict__ out, const UnitAddr& ua,
+                            long unit, const float v[13]) {
+    if (P.rows == AC_ROWS_PLAIN) { store_rows<13>(out, ua, v); return; }
+    float r[13];
+    if (P.rows == AC_ROWS_DEFECT) {
+        UnitAddr un = ua;
+        un.q += 1;
+        float xn[13];
+        load_rows<13>(X, un, xn);
+#pragma unroll
+        for (int i = 0; i < 13; ++i) r[i] = xn[i] - v[i];
+    } else {
+        UnitAddr up = ua;
+        up.q -= 1;
+        float x1[13], x0[13];
+        load_rows<13>(X, ua, x1);
+        load_rows<13>(X, up, x0);
+        const float dtk = P.rows_dt_per_unit ? P.rows_dt_per_unit[unit] : P.rows_dt;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) r[i] = fmaf(-dtk, v[i], x1[i] - x0[i]);
+    }
+    store_rows<13>(out, ua, r);
+}
 // flat [ROWS][n] helper used by the rollout kernels
 template <int ROWS> AC_DI void load_rows(const float* __restrict__ src, long n, long i, float out[ROWS]) {
 #pragma unroll
@@ -58,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void k_state_derivative(const DevParams P, 
     AnalyticCoeffs<MODEL> coeffs;
     coeffs.prefetch(P, x, u);
     state_derivative<float>(P, coeffs, x, u, xd);
-    store_rows<13>(Xdot, ua, xd);
+    store_state_rows(P, X, Xdot, ua, i, xd);
 }
 
 template <int MODEL>
@@ -75,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void k_step(const DevParams P, const float*
     const float h = dt_per_unit ? dt_per_unit[i] : dt;
     AnalyticCoeffs<MODEL> coeffs;
     state_update(P, coeffs, x, u, h);
-    store_rows<13>(Xn, ua, x);
+    store_state_rows(P, X, Xn, ua, i, x);
 }
 
 // Sequential-in-k rollout: the state stays in registers, u_k streams in, x_{k+1} streams out
@@ -149,8 +177,10 @@ template <int N, bool QUAD = false> struct SensIOT {
 
     // Store this lane's N tangent columns of the 13 outputs (+ its share of the constant columns).
     // p_diag: the diagonal of the constant position block — 1 for the step (dF/dp = [I; 0]), 0 for f itself (df/dp = 0)
+    // scale, diag: the stored Jacobian is  scale * J + diag * I  (the implicit defect rows store I - dt Fx and -dt Fu)
     static AC_DI void store(int g, const UnitAddr& ua, const Dual<N> x[13], float* __restrict__ A,
-                            float* __restrict__ Bm, float* __restrict__ c, bool constants, float p_diag = 1.f) {
+                            float* __restrict__ Bm, float* __restrict__ c, bool constants, float p_diag = 1.f,
+                            float scale = 1.f, float diag = 0.f) {
         const long n = ua.blk;  // row stride
         float* Au = A + ua.off(169);
         float* Bu = Bm + ua.off(91);
@@ -160,8 +190,13 @@ template <int N, bool QUAD = false> struct SensIOT {
             float* base; long stride;
             column(N * g + j, n, Au, Bu, cu, base, stride);
             if (base) {
+                const int d = N * g + j;
 #pragma unroll
-                for (int i = 0; i < 13; ++i) base[(long)i * stride] = x[i].d[j];
+                for (int i = 0; i < 13; ++i) {
+                    float v = x[i].d[j];
+                    if (scale != 1.f || diag != 0.f) v = fmaf(scale, v, (d < 10 && i == 3 + d) ? diag : 0.f);
+                    base[(long)i * stride] = v;
+                }
             }
         }
         if (constants && g < 3) {
@@ -290,10 +325,26 @@ AC_DI void deriv_seeded(const DevParams& P, Coeffs& coeffs, int g, const float x
     state_derivative(P, coeffs, xs, u, k);
 }
 
+// X: the kernel's node-major input (for the implicit rows: nodes 1 .. H, see store_state_rows)
 template <int N, bool QUAD>
-AC_DI void deriv_store(int g, const UnitAddr& ua, const Dual<N> k[13], float* __restrict__ Xdot, float* __restrict__ Fx,
-                       float* __restrict__ Fu) {
+AC_DI void deriv_store(const DevParams& P, const float* __restrict__ X, long unit, int g, const UnitAddr& ua,
+                       const Dual<N> k[13], float* __restrict__ Xdot, float* __restrict__ Fx, float* __restrict__ Fu) {
     const UnitAddr uo = ua.late();
+    if (P.rows == AC_ROWS_IMPLICIT) {
+        // r = x_{k+1} - x_k - dt f,  d r / d x_{k+1} = I - dt Fx,  d r / d u = -dt Fu,  d r / d dt = -f   (control/base.py:282-284)
+        const float dtk = P.rows_dt_per_unit ? P.rows_dt_per_unit[unit] : P.rows_dt;
+        if (g == 0) {
+            float f[13];
+#pragma unroll
+            for (int i = 0; i < 13; ++i) f[i] = k[i].v;
+            store_state_rows(P, X, Xdot, uo, unit, f);
+            float* p = P.rows_aux + uo.off(13);
+#pragma unroll
+            for (int i = 0; i < 13; ++i) p[(long)i * uo.blk] = -f[i];
+        }
+        SensIOT<N, QUAD>::store(g, uo, k, Fx, Fu, nullptr, true, 1.f, -dtk, 1.f);  // (d/dp: I - dt 0)
+        return;
+    }
     if (g == 0) {
         float* p = Xdot + uo.off(13);
 #pragma unroll
@@ -321,7 +372,7 @@ __global__ __launch_bounds__(kBlock, kSensWavesPerSimd) void k_deriv_sens(const 
     Dual<kAnN> k[13];
     AnalyticCoeffs<MODEL> coeffs;
     deriv_seeded<kAnN>(P, coeffs, g, xv, uv, k);
-    if (live) deriv_store<kAnN, MODEL == AC_MODEL_QUAD>(g, ua, k, Xdot, Fx, Fu);
+    if (live) deriv_store<kAnN, MODEL == AC_MODEL_QUAD>(P, X, unit, g, ua, k, Xdot, Fx, Fu);
 }
 
 // ---- envelope rows of AircraftControl.state_constraint (control/aircraft.py:44-59) and their state Jacobian ---------
@@ -382,13 +433,18 @@ AC_DI float envelope_violation(const EnvelopePenalty& E, int r, float g) {
 // — the same quadratic penalty on bounds SHIFTED inwards by lam / 2w, so cost, gradient and Gauss-Newton curvature are the
 // penalty kernels' with a shifted violation; the first-order multiplier update lam <- max(0, lam + 2w (g - hi)) is
 // lam <- 2w x (that shifted violation).  lam [H+1][8][B]: rows 0-3 upper, 4-7 lower bounds; NULL = plain penalty.
-struct ShiftedViolation { float v, const_term; };
+// Both sides are evaluated on their own (with large multipliers on a narrow row both shifted bounds can be violated at once):
+//   v = max(0, up) - max(0, dn)  (gradient 2 w v grad g),  sq = max(0, up)^2 + max(0, dn)^2  (cost),  active = sides violated
+//   (Gauss-Newton curvature 2 w active grad g grad g').
+struct ShiftedViolation { float v, sq, active, const_term; };
 AC_DI ShiftedViolation envelope_violation_al(const EnvelopePenalty& E, int r, float g, float lam_hi, float lam_lo) {
     const float i2w = E.weight > 0.f ? 0.5f / E.weight : 0.f;
     const float sh = lam_hi * i2w, sl = lam_lo * i2w;
-    const float up = g - E.hi[r] + sh, dn = E.lo[r] - g + sl;   // at most one of them is positive for lo < hi and small shifts
+    const float up = fmaxf(0.f, g - E.hi[r] + sh), dn = fmaxf(0.f, E.lo[r] - g + sl);
     ShiftedViolation o;
-    o.v = up > 0.f ? up : (dn > 0.f ? -dn : 0.f);
+    o.v = up - dn;
+    o.sq = fmaf(up, up, dn * dn);
+    o.active = (up > 0.f ? 1.f : 0.f) + (dn > 0.f ? 1.f : 0.f);
     o.const_term = sh * sh + sl * sl;
     return o;
 }
@@ -420,7 +476,7 @@ __global__ __launch_bounds__(kBlock) void k_envelope_cost(const DevParams P, con
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const ShiftedViolation sv = envelope_violation_al(E, r, g[r], lh[r], ll[r]);
-            acc = fmaf(sv.v, sv.v, acc) - sv.const_term;
+            acc = (acc + sv.sq) - sv.const_term;
         }
     }
     cost[i] += E.weight * acc;
@@ -478,11 +534,12 @@ __global__ __launch_bounds__(kBlock) void k_envelope_model(const DevParams P, co
     AeroPre<T> a;
     aero_pre(P, x, a);
     const T row[3] = {a.vr[0] * a.vr[0] + a.vr[1] * a.vr[1] + a.vr[2] * a.vr[2], a.beta, a.alpha};
-    float viol[4], grad[4][13], lh[4], ll[4];
+    float viol[4], active[4], grad[4][13], lh[4], ll[4];
     load_multipliers(lam, k, b, B, lh, ll);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        viol[r] = envelope_violation_al(E, r, r < 3 ? row[r].v : xv[2], lh[r], ll[r]).v;
+        const ShiftedViolation sv = envelope_violation_al(E, r, r < 3 ? row[r].v : xv[2], lh[r], ll[r]);
+        viol[r] = sv.v; active[r] = sv.active;
 #pragma unroll
         for (int j = 0; j < 13; ++j) grad[r][j] = r < 3 ? ((j >= 3 && j < 10) ? row[r].d[j - 3] : 0.f) : (j == 2 ? 1.f : 0.f);
     }
@@ -501,13 +558,13 @@ __global__ __launch_bounds__(kBlock) void k_envelope_model(const DevParams P, co
         float* hz = Hz + k * 441 * B + b;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (viol[r] == 0.f) continue;
+            if (active[r] == 0.f) continue;
 #pragma unroll
             for (int i = 0; i < 13; ++i)
 #pragma unroll
                 for (int j = 0; j < 13; ++j) {
                     const float v = grad[r][i] * grad[r][j];
-                    if (v != 0.f) hz[(long)(i * 21 + j) * B] += w2 * v;
+                    if (v != 0.f) hz[(long)(i * 21 + j) * B] += (w2 * active[r]) * v;
                 }
         }
     }

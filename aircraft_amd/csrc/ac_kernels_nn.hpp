@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_deriv_sens(const DevParams P, 
     MlpCoeffs<MlpEngine<6, WT, USE_MFMA>> coeffs(eng);
     deriv_seeded<4>(P, coeffs, w.g, xv, uv, k);
     eng.drain();
-    if (w.live) deriv_store<4, false>(w.g, w.ua, k, Xdot, Fx, Fu);
+    if (w.live) deriv_store<4, false>(P, X, w.unit, w.g, w.ua, k, Xdot, Fx, Fu);
 }
 
 // The sensitivity step for a REMAINDER of units that would leave the last round of the grid half empty: a wave's time
@@ -242,12 +242,12 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_fwd(const DevParams P, const M
         coeffs.prefetch(P, x, u);
     state_derivative<float>(P, coeffs, x, u, xd);
         eng.drain();
-        if (w.live && w.g == 0) store_rows<13>(out, w.ua, xd);
+        if (w.live && w.g == 0) store_state_rows(P, X, out, w.ua, w.unit, xd);
     } else if constexpr (OP == OP_STEP) {
         const float h = dt_per_unit ? dt_per_unit[w.unit] : dt;
         state_update(P, coeffs, x, u, h);
         eng.drain();
-        if (w.live && w.g == 0) store_rows<13>(out, w.ua, x);
+        if (w.live && w.g == 0) store_state_rows(P, X, out, w.ua, w.unit, x);
     } else {
         coeffs.prefetch(P, x, u);
         AeroPre<float> a;
@@ -290,12 +290,12 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_fwd4(const DevParams P, const 
         coeffs.prefetch(P, x, u);
         state_derivative<float>(P, coeffs, x, u, xd);
         eng.drain();
-        if (live) store_rows<13>(out, ua.late(), xd);
+        if (live) store_state_rows(P, X, out, ua.late(), unit, xd);
     } else if constexpr (OP == OP_STEP) {
         const float h = dt_per_unit ? dt_per_unit[unit] : dt;
         state_update(P, coeffs, x, u, h);
         eng.drain();
-        if (live) store_rows<13>(out, ua.late(), x);
+        if (live) store_state_rows(P, X, out, ua.late(), unit, x);
     } else {
         coeffs.prefetch(P, x, u);
         AeroPre<float> a;

@@ -801,7 +801,7 @@ __global__ __launch_bounds__(kBlock8) void k_nn_deriv_sens_tiled8(const DevParam
         Dual<2> k[13];
         deriv_seeded<2>(P, coeffs, w.g, xv, uv, k);
         grp = q.next(grp, ticket, next_ticket);  // before the stores (see k_nn_step_sens_tiled8)
-        if (w.live) deriv_store<2, false>(w.g, w.ua, k, Xdot, Fx, Fu);
+        if (w.live) deriv_store<2, false>(P, X, w.unit, w.g, w.ua, k, Xdot, Fx, Fu);
     }
 }
 
@@ -828,11 +828,11 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_fwd_tiled(const DevParams P, c
         float xd[13];
         coeffs.prefetch(P, x, u);
         state_derivative<float>(P, coeffs, x, u, xd);
-        if (live) store_rows<13>(out, ua.late(), xd);
+        if (live) store_state_rows(P, X, out, ua.late(), unit, xd);
     } else if constexpr (OP == OP_STEP) {
         const float h = dt_per_unit ? dt_per_unit[unit] : dt;
         state_update(P, coeffs, x, u, h);
-        if (live) store_rows<13>(out, ua.late(), x);
+        if (live) store_state_rows(P, X, out, ua.late(), unit, x);
     } else {
         coeffs.prefetch(P, x, u);
         AeroPre<float> a;

@@ -13,6 +13,7 @@
 #include "ac_kernels_analytic.hpp"
 #include "ac_nn_decl.hpp"
 #include "ac_ilqr.hpp"
+#include "ac_goal.hpp"
 #include "ac_track.hpp"
 #include "ac_hess.hpp"
 #include "ac_hess_nn.hpp"
@@ -699,6 +700,45 @@ int ac_shoot_step_f32(ac_handle* h, const float* X, const float* U, float dt, co
     return step_impl(h, X, U, dt, dt_per_unit, B * H, B, Xn, stream);
 }
 
+static int deriv_sens_impl(ac_handle* h, const float* X, const float* U, long n, long blk, float* Xdot, float* Fx,
+                           float* Fu, void* stream);
+
+// ---- the defect rows of multiple shooting, written by the step / derivative kernels themselves (control/base.py:275-286) ----
+namespace {
+struct RowsScope {  // the launch takes a copy of h->dp: set for the launches in scope, plain again afterwards
+    ac_handle* h;
+    RowsScope(ac_handle* h_, int rows, float dt, const float* dtp, float* aux) : h(h_) {
+        h->dp.rows = rows; h->dp.rows_dt = dt; h->dp.rows_dt_per_unit = dtp; h->dp.rows_aux = aux;
+    }
+    ~RowsScope() { h->dp.rows = AC_ROWS_PLAIN; h->dp.rows_dt = 0.f; h->dp.rows_dt_per_unit = nullptr; h->dp.rows_aux = nullptr; }
+};
+}  // namespace
+
+int ac_shoot_defect_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long B, long H,
+                        float* R, void* stream) {
+    if (!h || B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    RowsScope scope(h, AC_ROWS_DEFECT, 0.f, nullptr, nullptr);
+    return step_impl(h, X, U, dt, dt_per_unit, B * H, B, R, stream);
+}
+
+int ac_shoot_implicit_defect_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long B,
+                                 long H, float* R, void* stream) {
+    if (!h || B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    if (h && B * H == 0) return AC_OK;
+    if (!X) return AC_ERR_BAD_ARG;
+    RowsScope scope(h, AC_ROWS_IMPLICIT, dt, dt_per_unit, nullptr);
+    return derivative_impl(h, X + 13 * B, U, B * H, B > 0 ? B : 1, R, stream);  // f at the NEXT nodes, paired with u_k
+}
+
+int ac_shoot_implicit_rows_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long B,
+                               long H, float* R, float* Jnext, float* Ju, float* Jdt, void* stream) {
+    if (!h || B < 0 || H < 0) return AC_ERR_BAD_ARG;
+    if (h && B * H == 0) return AC_OK;
+    if (!X || !Jdt) return AC_ERR_BAD_ARG;
+    RowsScope scope(h, AC_ROWS_IMPLICIT, dt, dt_per_unit, Jdt);
+    return deriv_sens_impl(h, X + 13 * B, U, B * H, B > 0 ? B : 1, R, Jnext, Ju, stream);
+}
+
 int ac_aero_f32(ac_handle* h, const float* X, const float* U, long n, float* out, void* stream) {
     AC_ENTER(h);
     const long blk = n;
@@ -1354,6 +1394,10 @@ int ac_ilqr_accept_f32(ac_handle* h, const float* Jc, const float* J0, const flo
     if (h && B == 0) return AC_OK;
     if (!h || !Jc || !J0 || !Xc || !X || !Jout || (H > 0 && (!Uc || !U)) || n_alpha < 1 || n_alpha > 8 || B < 0 || H < 0)
         return AC_ERR_BAD_ARG;
+    // Jout is written by the row-0 workgroups while the others still read J0 and Jc to decide whether to copy: an aliased
+    // Jout tears the iterate
+    if (Jout == J0 || (Jout >= Jc && Jout < Jc + (long)n_alpha * B) || (Jc >= Jout && Jc < Jout + B))
+        return fail(AC_ERR_BAD_ARG, "ac_ilqr_accept_f32: Jout must not alias J0 or Jc");
     const long nrows = (H + 1) * 13 + H * 7;
     dim3 grid((unsigned)((B + 255) / 256), (unsigned)((nrows + kAcceptRows - 1) / kAcceptRows));
     hipLaunchKernelGGL(k_ilqr_accept, grid, 256, 0, (hipStream_t)stream, Jc, J0, Xc, Uc, n_alpha, B, H, X, U, Jout, improved);
@@ -1414,6 +1458,77 @@ int ac_ilqr_backward_newton_f32(ac_handle* h, const ac_ilqr_cost* cost, const fl
     else if (Hz) AC_BACKWARD(false, true);
     else AC_BACKWARD(false, false);
 #undef AC_BACKWARD
+    note_launch(h, "k_ilqr_backward", grid, 64, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+// ---- the goal-acquisition loss of the reference's MPC driver (main/control/control.py:44-68; ac_goal.hpp) ----------------
+static GoalLoss to_dev_goal(const ac_goal_loss* g) {
+    GoalLoss d;
+    static_assert(sizeof(GoalLoss) == sizeof(ac_goal_loss), "ac_goal_loss layout");
+    memcpy(&d, g, sizeof(d));
+    return d;
+}
+
+int ac_goal_cost_f32(ac_handle* h, const ac_goal_loss* loss, const float* goal, const float* lam, long Bn, const float* X,
+                     const float* U, long B, long H, float* cost_inout, void* stream) {
+    AC_ENTER(h);
+    if (h && B == 0) return AC_OK;
+    if (!h || !loss || !goal || !X || !U || !cost_inout || B < 0 || H < 1 || Bn < 1 || B % Bn != 0) return AC_ERR_BAD_ARG;
+    int rc = model_ready(h);
+    if (rc != AC_OK) return rc;
+    const int grid = (int)((B + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_goal_cost<0>, grid, kBlock, 0, (hipStream_t)stream, h->dp, to_dev_goal(loss), goal, lam, Bn, X, U, B, H,
+                       cost_inout);
+    note_launch(h, "k_goal_cost", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_goal_model_f32(ac_handle* h, const ac_goal_loss* loss, const float* goal, const float* lam, const float* X,
+                      const float* U, long B, long H, float* node_q, float* node_xref, float* node_glin, float* node_uglin,
+                      float* Hz, void* stream) {
+    AC_ENTER(h);
+    if (h && B == 0) return AC_OK;
+    if (!h || !loss || !goal || !X || !U || !node_q || !node_xref || !node_glin || !node_uglin || B < 0 || H < 1)
+        return AC_ERR_BAD_ARG;
+    int rc = model_ready(h);
+    if (rc != AC_OK) return rc;
+    const long n = (H + 1) * B;
+    const int grid = (int)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_goal_model<0>, grid, kBlock, 0, (hipStream_t)stream, h->dp, to_dev_goal(loss), goal, lam, X, U, B, H,
+                       node_q, node_xref, node_glin, node_uglin, Hz);
+    note_launch(h, "k_goal_model", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_goal_multiplier_f32(ac_handle* h, const ac_goal_loss* loss, const float* X, long B, long H, float* lam, float* viol,
+                           void* stream) {
+    AC_ENTER(h);
+    if (h && B == 0) return AC_OK;
+    if (!h || !loss || !X || !lam || B < 0 || H < 1) return AC_ERR_BAD_ARG;
+    const int grid = (int)((B + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_goal_multiplier<0>, grid, kBlock, 0, (hipStream_t)stream, to_dev_goal(loss), X, B, H, lam, viol);
+    note_launch(h, "k_goal_multiplier", grid, kBlock, 0);
+    AC_HIP(hipGetLastError());
+    return AC_OK;
+}
+
+int ac_ilqr_backward_goal_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* node_q, const float* node_xref,
+                              const float* node_glin, const float* node_uglin, const float* Hz, const float* X,
+                              const float* U, const float* A, const float* Bm, long B, long H, float* K, float* kff,
+                              float* dV, void* stream) {
+    AC_ENTER(h);
+    if (h && B == 0) return AC_OK;
+    if (!h || !cost || !node_q || !node_xref || !node_glin || !Hz || !X || !U || !A || !Bm || !K || !kff || !dV || B < 0 || H < 1)
+        return AC_ERR_BAD_ARG;
+    NodeCost nc{node_q, node_xref, node_glin, B};
+    nc.uglin = node_uglin;
+    const int grid = (int)B;  // one wave per instance
+    hipLaunchKernelGGL((k_ilqr_backward<true, true>), grid, 64, 0, (hipStream_t)stream, to_dev_cost(cost), nc, X, U, A, Bm, Hz,
+                       B, H, K, kff, dV);
     note_launch(h, "k_ilqr_backward", grid, 64, 0);
     AC_HIP(hipGetLastError());
     return AC_OK;

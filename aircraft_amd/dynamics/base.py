@@ -64,6 +64,31 @@ def _torch():
     return torch
 
 
+# Handles whose release was requested while a stream was capturing.  ac_destroy frees device memory (hipFree), which is
+# not permitted while a capture is open and invalidates it ("operation failed due to a previous error during capture") —
+# and a release can be requested at any point of a capture: a cyclic-GC pass or a refcount reaching zero runs
+# SixDOF.__del__ wherever it happens to.  Such handles are parked here and destroyed by the next call that finds no
+# capture open (_drain_parked: every _sync(), every close()).
+_PARKED: list = []
+
+
+def _capturing() -> bool:
+    import sys
+
+    torch = sys.modules.get("torch")
+    try:
+        return bool(torch is not None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+    except Exception:
+        return False
+
+
+def _drain_parked() -> None:
+    if _PARKED and not _capturing():
+        lib = _lib.load()
+        while _PARKED:
+            lib.ac_destroy(_PARKED.pop())
+
+
 class SixDOF(ABC):
     """Base class for batched 6-DoF dynamics in a NED frame."""
 
@@ -105,6 +130,7 @@ class SixDOF(ABC):
     def _sync(self):
         """Create the handle on first use; re-send constants if any attribute changed since the last call."""
         lib = _lib.load()
+        _drain_parked()
         p = self._param_struct()
         key = bytes(p)
         torch = _torch()
@@ -121,11 +147,15 @@ class SixDOF(ABC):
 
     def close(self):
         if getattr(self, "_handle", None):
-            _lib.load().ac_destroy(self._handle)
+            if _capturing():
+                _PARKED.append(C.c_void_p(self._handle.value))  # destroyed after the capture (see _PARKED)
+            else:
+                _lib.load().ac_destroy(self._handle)
             self._handle = C.c_void_p()
             # the workspaces died with the handle: a re-created one must be reserved again
             self._hess_reserved = 0
             self._installed_key = None
+        _drain_parked()
 
     def __del__(self):
         try:

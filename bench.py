@@ -203,8 +203,36 @@ def cpu_baseline(ac, X, U, dt, seconds):
 
     res = leg(all_threads, 0.5 * seconds, keep=True)
     res["one_core"] = leg(1, 0.5 * seconds)
+    res["cfg1_per_call"] = cfg1_per_call(orc)
     orc.set_num_threads(all_threads)
     return res, kept
+
+
+def cfg1_per_call(orc, seconds=1.0):
+    """BASELINE configs[0] in the shape the reference actually runs it — ONE glider, H = 20, analytic
+    (default) coefficients, one call of the step per node in a host loop (main/control/control.py:72-93), float64 oracle on
+    one core.  The reference's own figure for this loop is ~4.5e5 steps/s in the CasADi VM."""
+    import numpy as np
+    from aircraft_amd import Aircraft, AircraftConfiguration, AircraftOpts
+    from aircraft_amd.synthetic import GLIDER
+
+    ac1 = Aircraft(AircraftOpts(coeff_model_type="default", aircraft_config=AircraftConfiguration(dict(GLIDER)),
+                                physical_integration_substeps=1))
+    o = orc.for_aircraft(ac1)
+    orc.set_num_threads(1)
+    x0 = np.array([0, 0, -200, 50, 0, 0, 0, 0, 0, 1, 0, 0, 0], dtype=np.float64)[:, None]
+    u = np.array([0, 3, 0, 0, 0, 0, 0], dtype=np.float64)[:, None]
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < seconds:
+        x = x0
+        for _ in range(20):
+            x = o.state_update(x, u, 0.01)
+        reps += 1
+    el = time.perf_counter() - t0
+    return {"value": 20 * reps / el, "unit": "horizon-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} rollouts of B=1 x H=20 (trim state, elevator 3 deg, default model), one oracle call per node "
+                      f"from a Python loop, {el:.1f} s", "us_per_call": el / (20 * reps) * 1e6}
 
 
 def parity_in_run(kept, F, A, Bm, tol=1e-5):
@@ -232,8 +260,31 @@ def parity_in_run(kept, F, A, Bm, tol=1e-5):
     finite = bool(np.isfinite(Fg).all() and np.isfinite(Ag).all() and np.isfinite(Bg).all())
     return {"units": int(n), "state_block_rel_max": worst, "A_unit_rel_max": ea, "B_unit_rel_max": eb, "tol": tol,
             "ok": bool(finite and worst <= tol and ea <= tol and eb <= tol),
-            "note": "timed run's F, A, B (last sweep, still in HBM) vs the float64 oracle on the same first `units` "
-                    "(x_k,u_k) units; every unit on its own (max norm), nothing masked"}
+            "note": "F, A, B exactly as the last TIMED sweep left them in HBM (the alongside passes write other buffers) vs the "
+                    "float64 oracle on the same first `units` (x_k,u_k) units; every unit on its own (max norm), nothing masked"}
+
+
+def strong_model(batch, H, world, headline_kernel, cus=256):
+    """What DESIGN.md §7 predicts for the strong-scaled job before launch and gather costs, so that a SCALE run explains
+    itself: the headline kernel runs in rounds of 64 units per CU; a remainder of at most half a round goes to the
+    wave-pair kernel at ~0.58 of a round, a larger one costs a whole round."""
+    if not headline_kernel:
+        return None
+    per_round = 64 * cus
+
+    def cost(units):
+        full, rem = divmod(units, per_round)
+        return full + (0.0 if rem == 0 else (0.58 if rem <= per_round // 2 else 1.0))
+
+    one = cost(batch * H)
+    out = {"round_units": per_round, "rounds_one_gpu": batch * H / per_round, "cost_one_gpu_rounds": one, "per_n": {}}
+    for n in (1, 2, 4, 8):
+        units = -(-batch // n) * H
+        out["per_n"][str(n)] = {"rounds_per_rank": units / per_round, "cost_rounds": cost(units), "predicted_speedup": one / cost(units)}
+    out["this_run"] = out["per_n"].get(str(world))
+    out["note"] = ("predicted_speedup excludes launch and the one all-gather per solve (gather_ms); >= 6x at N = 8 has under "
+                   "5 % margin (DESIGN.md §7)")
+    return out
 
 
 # ---- one rank ----------------------------------------------------------------------------------------------------
@@ -370,7 +421,8 @@ def run_rank(args):
         return e0.elapsed_time(e1) / iters
     traj = torch.empty((H + 1, 13, B), device=dev)
     x0 = X[0].contiguous()
-    fwd_ms = _time(lambda: ms.propagate(X, U, out=Fbuf))
+    Falong = torch.empty_like(Fbuf)  # the alongside passes write HERE: F, A, B of the timed sweeps stay as the timed kernel left them
+    fwd_ms = _time(lambda: ms.propagate(X, U, out=Falong))
     roll_ms = _time(lambda: ms.rollout(x0, U, out=traj), 5)
 
     # HBM traffic of the dominant kernel from the PMC passes (FETCH_SIZE x2 per the gfx950 guide + WRITE_SIZE, calibrated
@@ -380,7 +432,7 @@ def run_rank(args):
     from aircraft_amd.build import source_sha
     this_build = source_sha()
     if (B, H, hidden) == (4096, 50, (128, 128, 128, 128)) and not args.no_mfma and not os.environ.get("AIRCRAFT_HIP_LIB"):
-        for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", cand)
             if not os.path.exists(tpath):
                 continue
@@ -426,6 +478,8 @@ def run_rank(args):
             res["gather_note"] = ("rank 0, HIP events around the path's one exchange, once per solve inside the timed region: "
                                   "k_traj_cost + k_best_records (select + pack) + one all_gather_into_tensor of the "
                                   f"{(1 + (H + 1) * 13 + H * 7) * 4} B record per rank + k_merge_records")
+        if world > 1:
+            res["strong_model"] = strong_model(args.batch, H, world, hidden == (128, 128, 128, 128) and not args.no_mfma)
         if "strong" in results and scaling != "strong":
             s = results["strong"]
             res["strong"] = {"value": s["value"], "unit": "horizon-steps/s", "scaling": "strong",
@@ -447,9 +501,7 @@ def run_rank(args):
             Uh = primary["Uh"].astype(np.float32).astype(np.float64)
             Xs = Xh[:H].transpose(1, 0, 2).reshape(13, H * B)
             Us = Uh.transpose(1, 0, 2).reshape(7, H * B)
-            # the alongside passes above wrote F (forward shooting) again — bit-identical by construction, but the
-            # check is on what the timed kernel itself produces: one more sweep of it, outside the timed region
-            ms.linearise(X, U, out=(Fbuf, primary["A"], primary["Bm"], None)); torch.cuda.synchronize()
+            # F, A, B are still what the LAST TIMED sweep wrote (nothing after the timed region writes them)
             res["cpu_baseline"], kept = cpu_baseline(ac, np.ascontiguousarray(Xs), np.ascontiguousarray(Us), dt,
                                                      args.cpu_seconds)
             res["parity_in_run"] = parity_in_run(kept, Fbuf, primary["A"], primary["Bm"])

@@ -23,7 +23,14 @@
  *   - return value: AC_OK (0) or a negative ac_status; nothing is thrown across the ABI.  NaNs in the
  *     inputs propagate to the outputs unchanged (the reference's callers test np.isnan,
  *     main/dynamics/dynamics.py:108).
- *   - thread-compatible per handle: no global mutable state.
+ *   - thread-compatible per handle: no global mutable state.  A handle does own mutable DEVICE state that its
+ *     launches share, so launches of ONE handle must be ordered on ONE stream (or otherwise serialised) where they use it:
+ *       * the ticket counter of the persistent vector-ALU kernels of an MLP set with use_mfma = 0 (ac_step_sens_f32,
+ *         ac_shoot_sens_f32, ac_*_derivative_sens_f32 on hidden widths <= 64): 0 between launches, drawn from by every
+ *         wave of a launch and reset by the wave that draws the last ticket.  Two launches of one handle running
+ *         concurrently on two streams would skip or duplicate unit groups; use one handle per stream;
+ *       * the second-order workspace (ac_reserve_hess_workspace; see ac_step_hess_f32).
+ *     ac_destroy / ac_set_* free or replace device memory: never while a stream of the process is capturing.
  */
 #ifndef AIRCRAFT_HIP_H
 #define AIRCRAFT_HIP_H
@@ -221,6 +228,21 @@ int ac_reserve_hess_workspace(ac_handle* h, long n);
 int ac_shoot_hess_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit,
                       const float* lambda, long B, long H, float* Hout, void* stream);
 
+/* The defect rows of multiple shooting, written by the step / derivative kernels themselves
+ *                                                  — ControlProblem.state_constraint, control/base.py:275-286.
+ * X [H+1][13][B] (every node), U [H][7][B]; dt / dt_per_unit [H][B] as in ac_shoot_step_f32.  R [H][13][B]:
+ *   ac_shoot_defect_f32             R_k = x_{k+1} - F(x_k, u_k, dt_k)                   ('explicit', :279-280)
+ *   ac_shoot_implicit_defect_f32    R_k = x_{k+1} - x_k - dt_k f(x_{k+1}, u_k)          ('implicit', :282-284)
+ *   ac_shoot_implicit_rows_f32      the same R with its Jacobian blocks: Jnext [H][13][13][B] = d R_k / d x_{k+1} =
+ *                                   I - dt_k Fx, Ju [H][13][7][B] = d R_k / d u_k = -dt_k Fu, Jdt [H][13][B] =
+ *                                   d R_k / d dt_k = -f  (d R_k / d x_k = -I is not stored). */
+int ac_shoot_defect_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long B, long H,
+                        float* R, void* stream);
+int ac_shoot_implicit_defect_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long B,
+                                 long H, float* R, void* stream);
+int ac_shoot_implicit_rows_f32(ac_handle* h, const float* X, const float* U, float dt, const float* dt_per_unit, long B,
+                               long H, float* R, float* Jnext, float* Ju, float* Jdt, void* stream);
+
 /* Getters, out [22][n]: v_frd_rel(3), airspeed, alpha, beta, qbar, coefficients(6), forces_frd(3), moments_frd(3),
  * phi, theta, psi (Euler angles of q)        — dynamics/base.py:147-278, dynamics/aircraft.py:255-330, base.py:179-195 */
 int ac_aero_f32(ac_handle* h, const float* X, const float* U, long n, float* out, void* stream);
@@ -278,7 +300,8 @@ int ac_rollout_policy_f32(ac_handle* h, const ac_ilqr_cost* limits, const float*
  * Uc [H][7][n_alpha*B] (the layout ac_rollout_policy_f32 writes) with cost Jc [n_alpha*B]; J0 [B] is the cost of the
  * current iterate X [H+1][13][B], U [H][7][B].  Per instance: best = min_a Jc (non-finite costs never win, ties -> the
  * lowest a); if best < J0 the candidate's columns replace the iterate's IN PLACE.  Jout [B] = the accepted cost,
- * improved [B] = 0/1 bytes (may be NULL). */
+ * improved [B] = 0/1 bytes (may be NULL).  Jout must not alias J0 or Jc (AC_ERR_BAD_ARG): the workgroups that copy the
+ * rows re-read both while Jout is being written. */
 int ac_ilqr_accept_f32(ac_handle* h, const float* Jc, const float* J0, const float* Xc, const float* Uc, int n_alpha,
                        long B, long H, float* X, float* U, float* Jout, unsigned char* improved, void* stream);
 
@@ -292,6 +315,37 @@ int ac_ilqr_backward_node_f32(ac_handle* h, const ac_ilqr_cost* cost, const floa
 int ac_ilqr_cost_node_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* node_q, const float* node_xref,
                           const float* node_glin, long Bn, const float* X, const float* U, long B, long H, float* out,
                           void* stream);
+
+/* The goal-acquisition loss of the reference's MPC driver — Controller.loss, main/control/control.py:44-68:
+ *   J = w_goal |p_xy(N) - goal|^2 + w_rate sum_k sum_i l0(u_{k+1,i} - u_{k,i}; eps_rate) + w_height (z_N - z_0)^2
+ *       - (w_speed / N) sum_{k<N} v_rel(x_k).v_rel(x_k) + w_vx v_x(N) + w_vyz (v_y(N)^2 + v_z(N)^2),   l0(d) = 1 - exp(-d^2/eps),
+ *   subject to v_x(N) < vx_max (augmented Lagrangian, weight w_al, one multiplier per instance; w_al = 0: not enforced).
+ * Reference values: w_goal 1000, w_rate 100, eps_rate 1e-2, w_height 1, w_speed 1/100, w_vx = vel_param * 1000, w_vyz 1000,
+ * vx_max -2; the time term 10000 T is the linear control cost of the time row (ac_ilqr_cost::u_lin).
+ *   ac_goal_cost_f32        cost_inout [B] += J of every column of X [H+1][13][B], U [H][7][B] (EXACT value); column o
+ *                           belongs to instance o % Bn: goal [2][Bn], lam [Bn] (NULL = zeros)
+ *   ac_goal_model_f32       the convex quadratic model around the iterate for the backward pass: WRITES node_q / node_xref /
+ *                           node_glin [H+1][13][B] and node_uglin [H][7][B] (control gradient of the rate term, neighbours
+ *                           held at the iterate), ADDS the rate term's Gauss-Newton curvature to the (u, u) diagonal of
+ *                           Hz [H][21][21][B] (zero it or fill it with ac_shoot_hess_f32 / ac_envelope_al_model_f32 first)
+ *   ac_goal_multiplier_f32  lam <- max(0, lam + 2 w_al (v_x(N) - vx_max)); viol [B] (may be NULL) = the excess before it
+ *   ac_ilqr_backward_goal_f32  ac_ilqr_backward_newton_f32 with node_uglin added to Q_u */
+typedef struct ac_goal_loss {
+    float w_goal, w_rate, eps_rate, w_height, w_speed, w_vx, w_vyz;
+    float vx_max, w_al;
+    int time_row;   /* control row carrying dt_k, excluded from the rate term; <= 0: none */
+} ac_goal_loss;
+int ac_goal_cost_f32(ac_handle* h, const ac_goal_loss* loss, const float* goal, const float* lam, long Bn, const float* X,
+                     const float* U, long B, long H, float* cost_inout, void* stream);
+int ac_goal_model_f32(ac_handle* h, const ac_goal_loss* loss, const float* goal, const float* lam, const float* X,
+                      const float* U, long B, long H, float* node_q, float* node_xref, float* node_glin, float* node_uglin,
+                      float* Hz, void* stream);
+int ac_goal_multiplier_f32(ac_handle* h, const ac_goal_loss* loss, const float* X, long B, long H, float* lam, float* viol,
+                           void* stream);
+int ac_ilqr_backward_goal_f32(ac_handle* h, const ac_ilqr_cost* cost, const float* node_q, const float* node_xref,
+                              const float* node_glin, const float* node_uglin, const float* Hz, const float* X,
+                              const float* U, const float* A, const float* Bm, long B, long H, float* K, float* kff,
+                              float* dV, void* stream);
 
 /* Exact-Hessian (Newton / SQP) variant of the sweep, for the force models ac_shoot_hess_f32 supports:
  *   ac_ilqr_costate_f32        Lam [H][13][B]: multipliers of the defect rows at the current iterate,

@@ -48,9 +48,10 @@ def costate(c, X, A, node=None):
     return Lam
 
 
-def backward(c, X, U, A, Bm, node=None, Hz=None):
+def backward(c, X, U, A, Bm, node=None, Hz=None, uglin=None):
     """A (H,13,13,B), Bm (H,13,7,B) -> K (H,7,13,B), kff (H,7,B), dV (2,B).  Hz (H,21,21,B): optional second-order
-    dynamics blocks added to Qxx (rows/cols 0-12), Qux (rows 13-19, cols 0-12) and Quu (13-19, 13-19)."""
+    dynamics blocks added to Qxx (rows/cols 0-12), Qux (rows 13-19, cols 0-12) and Quu (13-19, 13-19).  uglin (H,7,B):
+    optional per-node control gradient added to Q_u (ac_ilqr_backward_goal_f32)."""
     H, _, B = U.shape
     q, qf, r = np.asarray(c.q, float), np.asarray(c.qf, float), np.asarray(c.r, float)
     K = np.zeros((H, 7, 13, B)); kff = np.zeros((H, 7, B)); dV = np.zeros((2, B))
@@ -65,6 +66,8 @@ def backward(c, X, U, A, Bm, node=None, Hz=None):
             if node is not None:
                 q = node[0][k, :, b]
                 lx = q * (X[k, :, b] - node[1][k, :, b]) + node[2][k, :, b]
+            if uglin is not None:
+                lu = lu + uglin[k, :, b]
             Qx = lx + Ak.T @ Vx; Qu = lu + Bk.T @ Vx
             Qxx = np.diag(q) + Ak.T @ Vxx @ Ak
             Qux = Bk.T @ Vxx @ Ak
@@ -115,10 +118,12 @@ def envelope_al(orc, X, lo, hi, w, lam=None):
         sh, sl = lam[k, :4] / (2 * w), lam[k, 4:] / (2 * w)
         up = rows - hi[:, None] + sh
         dn = lo[:, None] - rows + sl
-        v = np.where(up > 0, up, np.where(dn > 0, -dn, 0.0))
-        cost += w * ((v ** 2).sum(axis=0) - (sh ** 2).sum(axis=0) - (sl ** 2).sum(axis=0))
+        # straight from the formula: the two max() terms are independent (both can be positive once the shifts overlap)
+        vh, vl = np.maximum(0.0, up), np.maximum(0.0, dn)
+        v = vh - vl
+        cost += w * ((vh ** 2).sum(axis=0) + (vl ** 2).sum(axis=0) - (sh ** 2).sum(axis=0) - (sl ** 2).sum(axis=0))
         grad[k] = 2 * w * np.einsum("rb,rjb->jb", v, Jx)
-        curv[k] = 2 * w * np.einsum("rb,rib,rjb->ijb", (v != 0).astype(float), Jx, Jx)
+        curv[k] = 2 * w * np.einsum("rb,rib,rjb->ijb", (vh > 0).astype(float) + (vl > 0).astype(float), Jx, Jx)
         sv[k], rows_all[k] = v, rows
     return cost, grad, curv, sv, rows_all
 
@@ -128,3 +133,79 @@ def envelope_al_update(rows, lo, hi, w, lam):
     up = rows - hi[None, :, None]
     dn = lo[None, :, None] - rows
     return np.concatenate([np.maximum(0.0, lam[:, :4] + 2 * w * up), np.maximum(0.0, lam[:, 4:] + 2 * w * dn)], axis=1)
+
+
+# ---- the goal-acquisition loss of the reference's MPC driver (Controller.loss, /root/reference/main/control/control.py:44-68) ----
+# Written from the reference's formulas (not from ac_goal.hpp): l0_smooth (:22-23), goal_loss (:60), control_loss (:49-50),
+# height_loss (:67), speed_loss (:68-69), final_velocity_loss (:62-64), the constraint state[3, -1] < -2 (:55) as an
+# augmented-Lagrangian term.  Differences to the reference's shapes are stated in ac_goal.hpp (N controls, not N + 1).
+class GoalLoss:
+    def __init__(self, w_goal=1000.0, w_rate=100.0, eps_rate=1e-2, w_height=1.0, w_speed=0.01, w_vx=1000.0, w_vyz=1000.0,
+                 vx_max=-2.0, w_al=0.0, time_row=0):
+        self.w_goal, self.w_rate, self.eps_rate, self.w_height, self.w_speed = w_goal, w_rate, eps_rate, w_height, w_speed
+        self.w_vx, self.w_vyz, self.vx_max, self.w_al, self.time_row = w_vx, w_vyz, vx_max, w_al, time_row
+
+
+def l0_smooth(x, epsilon):
+    return 1.0 - np.exp(-x ** 2 / epsilon)
+
+
+def _rate_rows(g):
+    return [i for i in range(7) if not (g.time_row > 0 and i == g.time_row)]
+
+
+def goal_cost(orc, g, goal, X, U, lam=None):
+    """X (H+1,13,Bc), U (H,7,Bc), goal (2,Bn), lam (Bn,) -> (Bc,); column o belongs to instance o % Bn."""
+    H, _, Bc = U.shape
+    Bn = goal.shape[1]
+    gl = np.tile(goal, (1, Bc // Bn))
+    J = g.w_goal * ((X[H, 0] - gl[0]) ** 2 + (X[H, 1] - gl[1]) ** 2)
+    du = U[1:] - U[:-1]
+    J = J + g.w_rate * l0_smooth(du[:, _rate_rows(g)], g.eps_rate).sum(axis=(0, 1))
+    J = J + g.w_height * (X[H, 2] - X[0, 2]) ** 2
+    speed = np.zeros(Bc)
+    for k in range(H):
+        vr = orc.aero(X[k], np.zeros((7, Bc)))[:3]
+        speed += (vr * vr).sum(axis=0)
+    J = J - g.w_speed * speed / H
+    J = J + g.w_vx * X[H, 3] + g.w_vyz * (X[H, 4] ** 2 + X[H, 5] ** 2)
+    if g.w_al > 0:
+        s = (np.zeros(Bn) if lam is None else np.asarray(lam, float)) / (2 * g.w_al)
+        s = np.tile(s, Bc // Bn)
+        J = J + g.w_al * (np.maximum(0.0, X[H, 3] - g.vx_max + s) ** 2 - s ** 2)
+    return J
+
+
+def goal_model(orc, g, goal, X, U, lam=None):
+    """The quadratic model of ac_goal_model_f32 around (X, U): node_q, node_xref, node_glin (H+1,13,B), uglin (H,7,B) and
+    the rate curvature on the (u,u) diagonal (H,7,B)."""
+    H, _, B = U.shape
+    nq = np.zeros((H + 1, 13, B)); nx = np.zeros((H + 1, 13, B)); ng = np.zeros((H + 1, 13, B))
+    for k in range(H):
+        rows, Jx = orc.envelope(X[k])           # row 0 = v_rel . v_rel and its exact state Jacobian
+        ng[k] = -(g.w_speed / H) * Jx[0]
+    nq[H, 0] = nq[H, 1] = 2 * g.w_goal; nx[H, 0], nx[H, 1] = goal[0], goal[1]
+    nq[H, 2] = 2 * g.w_height; nx[H, 2] = X[0, 2]
+    nq[H, 4] = nq[H, 5] = 2 * g.w_vyz
+    ng[H, 3] = g.w_vx
+    if g.w_al > 0:
+        s = (np.zeros(B) if lam is None else np.asarray(lam, float)) / (2 * g.w_al)
+        act = X[H, 3] - g.vx_max + s > 0
+        nq[H, 3] = np.where(act, 2 * g.w_al, 0.0); nx[H, 3] = np.where(act, g.vx_max - s, 0.0)
+    eps = g.eps_rate
+    d = U[1:] - U[:-1]                          # (H-1, 7, B): d[k] = u_{k+1} - u_k
+    e = np.exp(-d ** 2 / eps)
+    gp = (2 * d / eps) * e                      # l0'
+    l0 = 1.0 - e
+    with np.errstate(divide="ignore", invalid="ignore"):
+        hp = np.where(l0 > 1e-12, gp ** 2 / (2 * np.maximum(l0, 1e-300)), (2 / eps) * e)   # Gauss-Newton curvature, -> 2/eps
+    ug = np.zeros((H, 7, B)); uh = np.zeros((H, 7, B))
+    ug[1:] += gp; ug[:-1] -= gp
+    uh[1:] += hp; uh[:-1] += hp
+    mask = np.zeros(7); mask[_rate_rows(g)] = 1.0
+    return nq, nx, ng, g.w_rate * ug * mask[None, :, None], g.w_rate * uh * mask[None, :, None]
+
+
+def goal_multiplier(g, X, lam):
+    exc = X[-1, 3] - g.vx_max
+    return np.maximum(0.0, lam + 2 * g.w_al * exc), np.maximum(0.0, exc)

@@ -212,3 +212,37 @@ def test_constraint_entry_points_status_codes(gpu):
     q._sync()
     assert lib.ac_envelope_f32(q._handle, p(X), 8, p(rows), None, st) == -3
     assert b"fixed-wing" in lib.ac_last_error()
+
+
+@pytest.mark.parametrize("name", ["poly", "real", "cfg2_3x64_valu"])
+def test_explicit_defect_rows_with_per_node_steps(gpu, name):
+    """opts['integration'] = 'explicit' with a step per node and instance (dt_k = 1 / progress_k^2, control/base.py:276):
+    r_k = x_{k+1} - F(x_k, u_k, dt_k) written by the step kernel itself (ac_shoot_defect_f32), against the oracle's step on
+    every (node, instance) pair; and the same rows through the implicit entry point with the same per-node steps."""
+    import torch
+    from aircraft_amd.control import MultipleShooting
+
+    ac = build(name)
+    B, H = 33, 7
+    X0, U = near_trim_problem(B, H, seed=9)
+    ms = MultipleShooting(system=ac, dt=0.01, num_nodes=H, opts={"quaternion": "constraint"})
+    Ud = dev(U, gpu)
+    X = ms.rollout(dev(X0, gpu), Ud)
+    X = (X + 1e-3 * torch.randn_like(X)).contiguous()      # off the rollout: the rows are not zero
+    dt = np.random.default_rng(4).uniform(4e-3, 1.2e-2, (H, B))
+    dtd = dev(dt, gpu)
+    r = ms.defects(X, Ud, dt=dtd, integration="explicit").cpu().numpy()
+    Xh, Uh, dth = X.cpu().numpy().astype(np.float64), f32_exact(U), f32_exact(dt)
+    orc = make_oracle(ac)
+    flat = lambda a, rows: np.ascontiguousarray(a.transpose(1, 0, 2).reshape(rows, H * B))  # noqa: E731
+    Fr = orc.state_update(flat(Xh[:-1], 13), flat(Uh, 7), dth.reshape(-1)).reshape(13, H, B).transpose(1, 0, 2)
+    scale = np.maximum(np.abs(Xh[1:]), 1.0).max()
+    assert np.abs(r - (Xh[1:] - Fr)).max() <= 1e-5 * scale
+    assert np.abs(r).max() > 1e-4
+    ri = ms.defects(X, Ud, dt=dtd, integration="implicit").cpu().numpy()
+    fr = orc.state_derivative(flat(Xh[1:], 13), flat(Uh, 7)).reshape(13, H, B).transpose(1, 0, 2)
+    assert np.abs(ri - ((Xh[1:] - Xh[:-1]) - dth[:, None, :] * fr)).max() <= 1e-5 * scale
+    r2, Jn, Ju, jdt = ms.linearise_implicit(X, Ud, dt=dtd)
+    assert float(np.abs(r2.cpu().numpy() - ri).max()) <= 2e-6 * scale
+    # (f on states 1e-3 off a rollout, block-relative with the omega_dot floor of 0.1: the derivative's own parity is test_state_derivative's)
+    assert block_rel_err(-jdt.cpu().numpy(), fr) < 1e-4

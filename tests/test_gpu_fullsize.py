@@ -379,8 +379,9 @@ def test_remainder_wave_pair_kernel_is_bit_identical(gpu, hidden, n):
     ragged = ac.step_sens(Xd, Ud, 0.01)
     if n % 16384:
         name = ac.last_launch()[0]
-        # (the folded 5-32-6 net has no hidden layer: the dispatcher keeps it on the one-wave kernel)
-        assert name == ("k_nn_step_sens_pair" if n < 16384 and hidden is not None else "k_nn_step_sens")
+        # (the folded 5-32-6 net is small enough for the two-waves-per-SIMD kernel, which takes every batch size itself)
+        want_name = "k_nn_step_sens_w2" if hidden is None else ("k_nn_step_sens_pair" if n < 16384 else "k_nn_step_sens")
+        assert name == want_name
     n_pad = -(-n // 16384) * 16384
     reps = -(-n_pad // n)
     Xp = Xd.repeat(1, reps)[:, :n_pad].contiguous()

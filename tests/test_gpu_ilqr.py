@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from tests.helpers import block_rel_err, f32_exact, make_aircraft, make_oracle, rel_fro
+from tests.helpers import block_rel_err, f32_exact, make_aircraft, make_oracle, rel_fro, synthetic_units
 
 pytestmark = pytest.mark.gpu
 
@@ -285,12 +285,16 @@ def test_envelope_al_kernels_match_numpy(gpu):
     ws = il._workspace(B, X.device)
     rng = np.random.default_rng(8)
     lam0 = f32_exact(rng.uniform(0, 1, (H + 1, 8, B)) * (rng.uniform(0, 1, (H + 1, 8, B)) < 0.5)
-                     * np.array([50.0, 0.05, 0.05, 2.0] * 2)[None, :, None])
+                     * np.array([50.0, 0.2, 0.05, 2.0] * 2)[None, :, None])
     lam0[:, 7] = 0.0  # (z has no lower bound: -1e30)
     ws["lam"].copy_(dev(lam0, gpu))
     orc = make_oracle(ac)
     cw, gw, pw, sv, rows = io.envelope_al(orc, Xh, lo, hi, w, lam0)
     assert (sv != 0).mean() > 0.15  # not vacuous: many shifted violations are active
+    # the beta row's shifts lam / 2w reach 0.033 > its half-width 0.01: at some nodes BOTH shifted bounds are violated, and
+    # the two max() terms of L_A must then both count (cost, gradient and curvature)
+    both = (rows[:, 1] - hi[1] + lam0[:, 1] / (2 * w) > 0) & (lo[1] - rows[:, 1] + lam0[:, 5] / (2 * w) > 0)
+    assert both.mean() > 0.02
     J = torch.full((B,), 7.0, device=gpu)
     il.envelope_cost(X, J)
     assert np.abs(J.cpu().numpy() - 7.0 - cw).max() <= 2e-5 * max(np.abs(cw).max(), 1.0)
@@ -451,3 +455,122 @@ def test_time_as_a_decision_variable_reaches_a_goal_the_fixed_step_cannot(gpu):
     assert (out["variable"][1] > 0.42).mean() > 0.9                          # by taking longer ...
     dtv = out["variable"][2]
     assert dtv.min() >= 0.005 - 1e-9 and dtv.max() <= 0.02 + 1e-9            # ... inside dt_bounds
+
+
+def test_handle_released_inside_a_plain_capture_does_not_invalidate_it(gpu):
+    """The last reference to an `Aircraft` dropped, and the cyclic collector run, INSIDE a plain torch.cuda.graph capture
+    (no quiet_capture): ac_destroy's hipFree would invalidate the capture; SixDOF.close() parks the handle instead and the
+    next call outside the capture destroys it.  The graph replays."""
+    import gc
+    import torch
+    from aircraft_amd.dynamics import base as dyn
+
+    victim = make_aircraft("default")
+    keeper = make_aircraft("default", normalise=True)
+    X, U = synthetic_units(64, seed=5)
+    Xd, Ud = dev(X, gpu), dev(U, gpu)
+    victim.state_update(Xd, Ud, 0.01)          # both handles exist on the device
+    out = keeper.state_update(Xd, Ud, 0.01)
+    ref = out.clone()
+    cyc = [victim]; cyc.append(cyc)            # only a cyclic collection can release it
+    del victim
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    parked_before = len(dyn._PARKED)
+    with torch.cuda.graph(g, stream=side):
+        del cyc
+        gc.collect()                           # finalises the victim while the stream is capturing
+        assert len(dyn._PARKED) >= parked_before + 1   # (the collection may also reach handles of earlier tests)
+        lib = keeper._sync()
+        from aircraft_amd import _lib as L
+        L.check(lib.ac_step_f32(keeper._handle, Xd.data_ptr(), Ud.data_ptr(), 0.01, None, 64, out.data_ptr(),
+                                keeper._stream()), "ac_step_f32")
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    keeper.state_update(Xd, Ud, 0.01)          # first call outside the capture drains the parked handle
+    assert len(dyn._PARKED) == 0
+
+
+def _goal_problem(gpu, B=10, H=14, model="poly"):
+    from aircraft_amd.control import GoalAcquisition
+    from tests.helpers import near_trim_problem
+
+    ac = make_aircraft(model, normalise=True)
+    X0, U = near_trim_problem(B, H, seed=6)
+    rng = np.random.default_rng(12)
+    U = f32_exact(U + rng.normal(0, 0.1, U.shape) * (np.arange(7) < 3)[None, :, None])
+    goal = f32_exact(np.stack([rng.uniform(5, 9, B), rng.uniform(-1, 1, B)]))
+    il = GoalAcquisition(system=ac, goal=goal, dt=0.01, num_nodes=H, vx_max=58.0, w_al=4.0, alphas=(1.0, 0.5, 0.1), reg=1.0)
+    return ac, il, f32_exact(X0), U, goal
+
+
+def test_goal_acquisition_kernels_match_numpy(gpu):
+    """The reference's goal-acquisition loss (Controller.loss, main/control/control.py:44-68) on the device against its
+    NumPy restatement (oracle/ilqr_oracle.py: goal_cost / goal_model / goal_multiplier, written from the reference's
+    formulas): exact value for an iterate and for a batch of line-search candidates that shares goals and multipliers; the
+    quadratic model (node arrays, control gradient of the rate term, its curvature on the (u,u) diagonal of Hz); the
+    multiplier update; and the backward pass fed that model against the NumPy Riccati pass."""
+    import torch
+    import ilqr_oracle as io
+
+    ac, il, X0, U, goal = _goal_problem(gpu)
+    B, H = U.shape[2], U.shape[0]
+    orc = make_oracle(ac)
+    Ud = dev(U, gpu)
+    X = il.rollout(dev(X0, gpu), Ud)
+    Xh = X.cpu().numpy().astype(np.float64)
+    g = il._goal_ws(B, gpu)
+    lam = f32_exact(np.random.default_rng(1).uniform(0, 40, B) * (np.arange(B) % 2))
+    g["lam"].copy_(dev(lam, gpu))
+    gl = io.GoalLoss(w_al=4.0, vx_max=58.0)
+    want = io.goal_cost(orc, gl, goal, Xh, U, lam)
+    got = il.trajectory_cost(X, Ud).cpu().numpy()
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+    act = Xh[-1, 3] - 58.0 + lam / 8.0 > 0
+    assert act.any() and (~act).any()      # the inequality is active for some instances only
+    X2, U2 = torch.cat([X, X], dim=2).contiguous(), torch.cat([Ud, 0.5 * Ud], dim=2).contiguous()
+    got2 = il.trajectory_cost(X2, U2).cpu().numpy()
+    want2 = np.concatenate([want, io.goal_cost(orc, gl, goal, Xh, 0.5 * U, lam)])
+    assert np.abs(got2 - want2).max() <= 2e-5 * np.abs(want2).max()
+    ws = il._workspace(B, gpu)
+    Hz = ws["Hz"].zero_()
+    ug = il._goal_model(X, Ud, Hz)
+    nq, nx, ng, ugw, uhw = io.goal_model(orc, gl, goal, Xh, U, lam)
+    f64 = lambda t: t.cpu().numpy().astype(np.float64)  # noqa: E731
+    assert np.abs(f64(g["nq"]) - nq).max() <= 1e-6 * np.abs(nq).max()
+    assert np.abs(f64(g["nx"]) - nx).max() <= 1e-6 * max(np.abs(nx).max(), 1.0)
+    assert np.abs(f64(g["ng"]) - ng).max() <= 2e-5 * np.abs(ng).max()
+    assert np.abs(f64(ug) - ugw).max() <= 2e-5 * max(np.abs(ugw).max(), 1.0)
+    Hh = f64(Hz)
+    diag = np.stack([Hh[:, 13 + i, 13 + i] for i in range(7)], axis=1)
+    assert np.abs(diag - uhw).max() <= 2e-5 * np.abs(uhw).max()
+    Hh[:, np.arange(13, 20), np.arange(13, 20)] = 0.0
+    assert not Hh.any()                    # nothing but the (u,u) diagonal is touched
+    # backward pass with the control gradient
+    F, A, Bm, _ = il.linearise(X, Ud, want_c=False)
+    node = (g["nq"], g["nx"], g["ng"])
+    K, kff, dV = il.backward(X, Ud, A, Bm, Hz=Hz, node=node, uglin=ug)
+    Hzw = np.zeros((H, 21, 21, B)); Hzw[:, np.arange(13, 20), np.arange(13, 20)] = uhw
+    Kr, kr, dVr = io.backward(il.cost, Xh, U, f64(A), f64(Bm), node=(nq, nx, ng), Hz=Hzw, uglin=ugw)
+    assert rel_fro(f64(K), Kr) < 2e-3 and rel_fro(f64(kff), kr) < 2e-3 and rel_fro(f64(dV), dVr) < 2e-3
+    K0, k0, _ = il.backward(X, Ud, A, Bm, Hz=Hz, node=node)
+    assert rel_fro(f64(kff), f64(k0)) > 1e-3   # the control gradient matters
+    viol = il.update_goal_multiplier(X).cpu().numpy()
+    lw, vw = io.goal_multiplier(gl, Xh, lam)
+    assert np.abs(g["lam"].cpu().numpy() - lw).max() <= 1e-5 * max(lw.max(), 1.0) and np.abs(viol - vw).max() <= 1e-5 * max(vw.max(), 1.0)
+
+
+def test_goal_acquisition_sweep_decreases_the_reference_loss(gpu):
+    """A few sweeps on the reference's goal-acquisition loss: the exact loss of every instance never increases within a
+    block of sweeps (the line search accepts only improvements), it decreases for most, and the solve stays finite."""
+    import torch
+
+    ac, il, X0, U, goal = _goal_problem(gpu, B=24, H=30)
+    X, Uo, hist = il.solve(dev(X0, gpu), dev(U, gpu), iters=6)
+    h = hist.cpu().numpy()
+    assert np.isfinite(h).all() and torch.isfinite(X).all()
+    assert (np.diff(h, axis=0) <= 1e-3 * np.abs(h[:-1])).all()
+    assert (h[-1] < h[0] - 1e-3 * np.abs(h[0])).mean() > 0.8

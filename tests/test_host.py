@@ -359,3 +359,44 @@ def test_quiet_capture_pauses_the_garbage_collector_and_restores_it(monkeypatch)
         assert not gc.isenabled()
     finally:
         gc.enable()
+
+
+def test_handle_release_is_parked_while_a_stream_is_capturing(monkeypatch):
+    """SixDOF.close() during a capture must not call ac_destroy (hipFree invalidates the capture): the handle is parked
+    and destroyed by the next call that finds no capture open.  Host logic only: the library is replaced by a recorder."""
+    import ctypes as C
+    from aircraft_amd.dynamics import base as dyn
+
+    destroyed = []
+
+    class FakeLib:
+        def ac_destroy(self, h):
+            destroyed.append(h.value if hasattr(h, "value") else h)
+            return 0
+
+    monkeypatch.setattr(dyn._lib, "load", lambda: FakeLib())
+    state = {"capturing": True}
+    monkeypatch.setattr(dyn, "_capturing", lambda: state["capturing"])
+    ac = make_aircraft("default")
+    ac._handle = C.c_void_p(0x1234)
+    ac.close()
+    assert destroyed == [] and [h.value for h in dyn._PARKED] == [0x1234] and not ac._handle
+    other = make_aircraft("default")
+    other._handle = C.c_void_p(0x5678)
+    state["capturing"] = False
+    other.close()                       # no capture open: destroys its own handle and drains the parked one
+    assert sorted(destroyed) == [0x1234, 0x5678] and dyn._PARKED == []
+
+
+def test_receding_horizon_refuses_a_variable_time_solver():
+    """The loop shifts / zeroes whole control columns and re-rolls at the fixed dt: a solver that carries dt_k in a control
+    row (ILQR(time='variable')) would be linearised at dt_k = 0 after a 'zero' warm start — refused, as MHTT refuses it."""
+    from aircraft_amd.control import RecedingHorizon
+
+    class Solver:
+        num_nodes, time_row = 50, 3
+
+    with pytest.raises(ValueError, match="fixed-time"):
+        RecedingHorizon(Solver(), overlap=30)
+    Solver.time_row = 0
+    assert RecedingHorizon(Solver(), overlap=30).keep == 20
