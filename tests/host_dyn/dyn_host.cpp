@@ -3,7 +3,7 @@
 // tangents of the RK4 step, lane group by lane group) against the float64 oracle without a GPU.  TEST INFRASTRUCTURE:
 // nothing in aircraft_amd loads this.
 #define AC_HOST_CHECK 1
-#include "../../aircraft_amd/csrc/ac_dynamics.hpp"
+#include "../../aircraft_amd/csrc/ac_adjoint.hpp"
 
 using namespace ac;
 
@@ -68,7 +68,65 @@ void run(const DevParams& P, int what, const float* X, const float* U, float dt,
     }
 }
 
+// gradient of lam . F over z = (x[13], u[7], dt) by the reverse sweep in plain floats, and its Hessian by the same sweep in
+// duals (N directions at a time) — ac_adjoint.hpp
+template <int MODEL, int N> void unit_adjoint(const DevParams& P, const float xv[13], const float uv[7], float dt, const float lam[13],
+                                              float grad[21], float Hm[441]) {
+    AdjAnalyticCoeffs<MODEL> coeffs;
+    {
+        float xo[13], gx[13], gu[7], gh;
+        rk4_vjp<float>(P, coeffs, xv, uv, dt, lam, xo, gx, gu, gh);
+        for (int i = 0; i < 13; ++i) grad[i] = gx[i];
+        for (int i = 0; i < 7; ++i) grad[13 + i] = gu[i];
+        grad[20] = gh;
+    }
+    for (int i = 0; i < 441; ++i) Hm[i] = 0.f;
+    for (int g = 0; g < (21 + N - 1) / N; ++g) {
+        typedef Dual<N> T;
+        T x[13], u[7], h(dt);
+        for (int i = 0; i < 13; ++i) x[i] = T(xv[i]);
+        for (int i = 0; i < 7; ++i) u[i] = T(uv[i]);
+        for (int j = 0; j < N; ++j) {
+            const int z = N * g + j;
+            if (z < 13) x[z].d[j] = 1.f;
+            else if (z < 20) u[z - 13].d[j] = 1.f;
+            else if (z == 20) h.d[j] = 1.f;
+        }
+        T xo[13], gx[13], gu[7], gh;
+        rk4_vjp<T>(P, coeffs, x, u, h, lam, xo, gx, gu, gh);
+        for (int j = 0; j < N; ++j) {
+            const int z = N * g + j;
+            if (z > 20) continue;
+            for (int i = 0; i < 13; ++i) Hm[i * 21 + z] = gx[i].d[j];
+            for (int i = 0; i < 7; ++i) Hm[(13 + i) * 21 + z] = gu[i].d[j];
+            Hm[20 * 21 + z] = gh.d[j];
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int host_dyn_adjoint(const ac_params* p, const float* linear_W, int N, const float* X, const float* U, float dt,
+                                const float* Lam, long n, float* grad /*[21][n]*/, float* Hm /*[21][21][n]*/) {
+    DevParams P{};
+    P.p = *p;
+    if (linear_W) for (int i = 0; i < 36; ++i) P.linear_W[i] = linear_W[i];
+    if (P.p.substeps > 1) return -1;
+    for (long u = 0; u < n; ++u) {
+        float xv[13], uv[7], lam[13], g[21], H[441];
+        for (int i = 0; i < 13; ++i) { xv[i] = X[i * n + u]; lam[i] = Lam[i * n + u]; }
+        for (int i = 0; i < 7; ++i) uv[i] = U[i * n + u];
+        bool done = false;
+#define AC_CASE(M_, N_) if (!done && P.p.model_kind == M_ && N == N_) { unit_adjoint<M_, N_>(P, xv, uv, dt, lam, g, H); done = true; }
+        AC_CASE(AC_MODEL_DEFAULT, 1) AC_CASE(AC_MODEL_DEFAULT, 2) AC_CASE(AC_MODEL_DEFAULT, 4)
+        AC_CASE(AC_MODEL_LINEAR, 1) AC_CASE(AC_MODEL_LINEAR, 2) AC_CASE(AC_MODEL_QUAD, 2)
+#undef AC_CASE
+        if (!done) return -2;
+        for (int i = 0; i < 21; ++i) grad[i * n + u] = g[i];
+        for (int i = 0; i < 441; ++i) Hm[i * n + u] = H[i];
+    }
+    return 0;
+}
 
 // what: 0 = one RK4 step with A, B, c (substeps must be 1); 1 = f with df/dx, df/du.  N = tangent directions per lane
 // group (2, 4 or 8).  Arrays component-major like the device ABI: X [13][n], A [13][13][n], ...

@@ -78,3 +78,50 @@ def test_device_math_derivative_sens_on_host(model, N):
     assert unit_max_rel(Xd, Xr).max() < 1e-5
     assert unit_max_rel(Fx, Fxr).max() < 1e-5
     assert unit_max_rel(Fu, Fur).max() < 1e-5
+
+
+def _run_adjoint(ac, N, X, U, dt, lam):
+    L = _lib()
+    fp = C.POINTER(C.c_float)
+    L.host_dyn_adjoint.restype = C.c_int
+    L.host_dyn_adjoint.argtypes = [C.c_void_p, fp, C.c_int, fp, fp, C.c_float, fp, C.c_long, fp, fp]
+    n = X.shape[1]
+    p = ac._param_struct()
+    d = ac.coefficient_model.oracle_data() or {}
+    W = np.ascontiguousarray(d["W"], dtype=np.float32) if "W" in d else None
+    Xf, Uf, Lf = (np.ascontiguousarray(a, dtype=np.float32) for a in (X, U, lam))
+    grad, Hm = np.zeros((21, n), dtype=np.float32), np.zeros((21, 21, n), dtype=np.float32)
+    rc = L.host_dyn_adjoint(C.byref(p), W.ctypes.data_as(fp) if W is not None else None, N, Xf.ctypes.data_as(fp),
+                            Uf.ctypes.data_as(fp), dt, Lf.ctypes.data_as(fp), n, grad.ctypes.data_as(fp), Hm.ctypes.data_as(fp))
+    assert rc == 0, rc
+    return grad, Hm
+
+
+@pytest.mark.parametrize("model,normalise,stall,N", [("default", True, False, 2), ("default", False, True, 4), ("linear", True, True, 2),
+                                                     ("default", True, True, 1)])
+def test_reverse_sweep_gradient_and_hessian_on_host(model, normalise, stall, N):
+    """ac_adjoint.hpp compiled for the host: the reverse sweep through the RK4 step in plain floats gives the gradient of
+    lambda . F — checked against the oracle's EXACT Jacobians, [A | B | c]' lambda — and the same sweep in duals gives the
+    second-order blocks, checked against central differences of those Jacobians (tests/helpers.py::oracle_step_hessian);
+    symmetric, zero rows for the position and the dead controls."""
+    from tests.helpers import oracle_step_hessian
+
+    ac = make_aircraft(model, normalise=normalise, stall_scaling=stall)
+    n = 40
+    X, U = _units(n, seed=31)
+    lam = f32_exact(np.random.default_rng(3).normal(size=(13, n)))
+    grad, Hm = _run_adjoint(ac, N, X, U, 0.01, lam)
+    orc = make_oracle(ac)
+    _, A, B, c = orc.step_sens(X, U, 0.01)
+    J = np.concatenate([A, B, c[:, None, :]], axis=1)          # (13, 21, n)
+    want = np.einsum("in,izn->zn", lam, J)
+    assert unit_max_rel(grad, want).max() < 2e-5
+    Hr = oracle_step_hessian(orc, X, U, 0.01, lam)
+    num = np.sqrt(((Hm - Hr) ** 2).sum(axis=(0, 1))); den = np.sqrt((Hr ** 2).sum(axis=(0, 1)))
+    rel = num / np.maximum(den, 1e-30)
+    if rel.max() >= 1e-3:   # (the checker's step across a |.| kink of the stall factors: see tests/test_gpu_fuzz.py)
+        Hr7 = oracle_step_hessian(orc, X, U, 0.01, lam, h=1e-7)
+        rel = np.minimum(rel, np.sqrt(((Hm - Hr7) ** 2).sum(axis=(0, 1))) / np.maximum(np.sqrt((Hr7 ** 2).sum(axis=(0, 1))), 1e-30))
+    assert rel.max() < 1e-3, (int(rel.argmax()), float(rel.max()))
+    assert np.abs(Hm - Hm.transpose(1, 0, 2)).max() <= 2e-4 * np.abs(Hm).max()
+    assert not Hm[:3].any() and not Hm[16:19].any()
