@@ -18,7 +18,7 @@
 #pragma once
 #include "ac_kernels_nn.hpp"
 #ifdef AC_EXP_ZERO_REGS
-#include "ac_exp_zero_regs.inc"
+#include "../../tools/experiments/ac_exp_zero_regs.inc"  // (experiment flavour only: not a product header)
 #endif
 
 namespace ac {
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors(const DevParams 
                                                                 float dt, const float* __restrict__ dt_per_unit, long n,
                                                                 long blk, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef AC_EXP_ZERO_REGS  // (experiment flavour only: tools/bisect_exp_last2.sh)
+#ifdef AC_EXP_ZERO_REGS  // (experiment flavour only: tools/archive/bisect_exp_last2.sh)
     AC_ZERO_ALL_REGS();
     for (int i = threadIdx.x; i < plan.lds_total / 4; i += blockDim.x) reinterpret_cast<volatile float*>(smem)[i] = 0.f;  // and the LDS
     __syncthreads();

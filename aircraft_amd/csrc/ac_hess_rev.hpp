@@ -26,7 +26,7 @@
 
 namespace ac {
 
-#ifdef AC_REV_CLOCKS  // (measurement flavour, tools/hess_rev_phases.sh: shader-clock cycles per phase of one wave, printed)
+#ifdef AC_REV_CLOCKS  // (measurement flavour, tools/archive/hess_rev_phases.sh: shader-clock cycles per phase of one wave, printed)
 #define AC_REV_TICK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); clk[i] += t_ - tlast; tlast = t_; } while (0)
 #else
 #define AC_REV_TICK(i) do { } while (0)
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_nn_stage_tensors_rev(const DevPar
                             acc[k >> 1][pi][k & 1] = fix ? E::curv_over_slope(y[k], rs[k]) * J[k][i] * J[k][j] : 0.f;
                 E::park(tot);
                 E::park(xs);
-#ifndef AC_REV_SKIP_CONTRACT  // (timing experiments only: tools/hess_rev_phases.sh)
+#ifndef AC_REV_SKIP_CONTRACT  // (timing experiments only: tools/archive/hess_rev_phases.sh)
                 eng.contract_top(wll, rs, acc);
 #endif
                 AC_REV_TICK(2);  // [2] top contraction

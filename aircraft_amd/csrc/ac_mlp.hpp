@@ -884,9 +884,9 @@ struct MlpEngine : TripleHolder<SECOND && NSLAB <= 10> {
             // SIFoldOperands of the ROCm 7.2.0 backend folds the 32-bit copies of their halves into accumulation registers
             // into a malformed `agpr_32 = REG_SEQUENCE` that loses the subregister index (both halves get the same value):
             // NaN / 1e19 from k_nn_stage_tensors<2,true,0> on single-layer nets.  Found by opt-bisect + MIR diff —
-            // profiles/r03_exp_last2_miscompile.txt, tools/bisect_exp_last2.sh; tools/check_sifold_regsequence.sh checks every
+            // profiles/r03_exp_last2_miscompile.txt, tools/archive/bisect_exp_last2.sh; tools/archive/check_sifold_regsequence.sh checks every
             // translation unit of the product for the malformed form.
-#ifdef AC_EXP_RUNTIME_ACT  // (experiment flavour: the form that exposes the defect, tools/bisect_exp_last2.sh)
+#ifdef AC_EXP_RUNTIME_ACT  // (experiment flavour: the form that exposes the defect, tools/archive/bisect_exp_last2.sh)
             layer<1, 1>(acquire(0), plan.act[0]);
 #else
             const char* wl1 = acquire(0);

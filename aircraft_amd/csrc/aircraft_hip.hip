@@ -264,7 +264,7 @@ int ac_create(const ac_params* params, ac_handle** out) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess) h->num_cus = cus;
     }
 #ifdef AC_DIAG_ENV
-    {   // measurement switches exist in the diagnostic flavours only (build.py --diag / tools/variant_lib.sh -DAC_DIAG_ENV):
+    {   // measurement switches exist in the diagnostic flavours only (build.py --diag / tools/archive/variant_lib.sh -DAC_DIAG_ENV):
         // the product library's dispatch never depends on the environment
         const char* e = getenv("AIRCRAFT_HIP_NO_PAIR");
         h->no_pair = e && e[0] == '1';
@@ -1214,7 +1214,7 @@ static int hess_single(ac_handle* h, const float* X, const float* U, float dt, c
                                    dt_per_unit, n, blk, h->rev_layers, h->d_rev_scratch, h->d_hess_ws);            \
             }
             if (!h->use_mfma) AC_REV_LAUNCH((k_nn_stage_tensors_rev3<8, false>))  // the cross-lane validation form of the product
-#ifdef AC_HESS_REV6  // (A/B flavour: the six-slab reverse sweep, tools/variant_lib.sh)
+#ifdef AC_HESS_REV6  // (A/B flavour: the six-slab reverse sweep, tools/archive/variant_lib.sh)
             else AC_REV_LAUNCH(k_nn_stage_tensors_rev<8>)
 #else
             else AC_REV_LAUNCH((k_nn_stage_tensors_rev3<8, true>))
