@@ -1083,6 +1083,17 @@ struct LdsAcc4 {
 };
 #endif
 
+// (diagnostic flavour: a phase stamp through the coefficient provider's engine, where it has one)
+template <class C, class = void> struct has_engine_stamper : std::false_type {};
+template <class C> struct has_engine_stamper<C, std::void_t<decltype(std::declval<C&>().eng.st)>> : std::true_type {};
+template <class C> AC_DI void provider_mark(C& coeffs, int id) {
+#ifdef AC_STAMPS
+    if constexpr (has_engine_stamper<C>::value) coeffs.eng.st.mark(id);
+#else
+    (void)coeffs; (void)id;
+#endif
+}
+
 // One RK4 step from primal inputs; xo = F(x0, u, h) with tangents w.r.t. this lane's N directions.
 template <int N, class Coeffs, class Acc>
 AC_DI void rk4_step_seeded(const DevParams& P, Coeffs& coeffs, int g, const float xv[13], const float uv[7],
@@ -1107,6 +1118,7 @@ AC_DI void rk4_step_seeded(const DevParams& P, Coeffs& coeffs, int g, const floa
             Seeds::template controls<Coeffs::kModel == AC_MODEL_QUAD>(gg, uv, u);
             state_derivative(P, coeffs, xs, u, k);
         }
+        if (s == 3) provider_mark(coeffs, 8);  // [8] the last stage's dual rigid body
         const float wsum = (s == 1 || s == 2) ? 2.0f : 1.0f;
         const float cnext = (s == 2) ? 1.0f : 0.5f;
         const T hs = Seeds::step(gg, hv * cnext, dh_ddt * cnext);
@@ -1115,6 +1127,7 @@ AC_DI void rk4_step_seeded(const DevParams& P, Coeffs& coeffs, int g, const floa
             acc.add(i, wsum, k[i]);
             xs[i] = dual_mul_add(hs, k[i], Seeds::state(gg, i, xv[i]));
         }
+        if (s == 3) provider_mark(coeffs, 9);  // [9] its RK4 accumulation
     }
     int ge = g;
     AC_OPAQUE_V(ge);  // the seeds of the final combination are rebuilt here, not carried across the four stages

@@ -359,10 +359,10 @@ __global__ __launch_bounds__(kBlock, kSensWavesPerSimd) void k_deriv_sens(const 
                                                        float* __restrict__ Xdot, float* __restrict__ Fx,
                                                        float* __restrict__ Fu) {
     constexpr int kAnN = AnalyticSensN<MODEL>::value;
-    constexpr int UPW = 4 * kAnN;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = lane % UPW, g = lane / UPW;
-    const long unit_raw = ((long)blockIdx.x * (kBlock / 64) + wave) * UPW + col;
+    static_assert(kBlock / 64 == 16 / kAnN, "one wave per direction group");
+    const int lane = threadIdx.x & 63;
+    const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave = direction group, lane = unit (see k_step_sens)
+    const long unit_raw = (long)blockIdx.x * 64 + lane;
     const bool live = unit_raw < n;
     const long unit = live ? unit_raw : n - 1;
     const UnitAddr ua(unit, blk);
@@ -630,10 +630,15 @@ __global__ __launch_bounds__(kBlock, kSensWavesPerSimd) void k_step_sens(const D
                                                       float* __restrict__ Xn, float* __restrict__ A,
                                                       float* __restrict__ Bm, float* __restrict__ c) {
     constexpr int kAnN = AnalyticSensN<MODEL>::value;
-    constexpr int UPW = 4 * kAnN;  // units per wave
+    constexpr int UPW = 4 * kAnN;  // units per wave (sub-stepped form)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = lane % UPW, g = lane / UPW;
-    const long unit_raw = ((long)blockIdx.x * (kBlock / 64) + wave) * UPW + col;
+    // One sub-step (every MPC driver): a WAVE is one direction group of 64 consecutive units (lane = unit), so every load and
+    // store instruction of a wave covers 256 contiguous bytes and the 0/1 seed pattern is wave-uniform.  Sub-stepped: the
+    // lanes of a unit share a wave (16 units x 4 groups), because the composition exchanges tangents across them.
+    static_assert(kBlock / 64 == 16 / kAnN, "one wave per direction group");
+    const int col = SUBSTEPPED ? lane % UPW : lane;
+    const int g = SUBSTEPPED ? lane / UPW : __builtin_amdgcn_readfirstlane(wave);
+    const long unit_raw = SUBSTEPPED ? ((long)blockIdx.x * (kBlock / 64) + wave) * UPW + col : (long)blockIdx.x * 64 + lane;
     const bool live = unit_raw < n;
     const long unit = live ? unit_raw : n - 1;  // clamp: dead lanes recompute the last unit, store nothing
     const UnitAddr ua(unit, blk);

@@ -30,9 +30,10 @@ s = stamps.cpu().numpy().astype(np.float64)
 nw = s[12]
 names = {0: "prologue (36 KB weight image -> LDS, barrier)", 1: "between forward() calls: dual rigid body + primal aero + z",
          3: "operand rows of layer 0 written", 2: "layer 0 (K = 8) + epilogue", 4: "hidden layers (2 x 16 k-steps + epilogues)",
-         5: "last layer (64 -> 6) + epilogue", 6: "outputs y, J read back", 7: "after the last stage: dual rigid body + RK4 combine"}
+         5: "last layer (64 -> 6) + epilogue", 6: "outputs y, J read back", 8: "last stage: dual rigid body after the network",
+         9: "last stage: RK4 accumulation", 7: "final combination + normalisation, up to the stores"}
 tot = s[:12].sum()
 print(f"B={B}: {name} {e0.elapsed_time(e1):.3f} ms ; waves {int(nw)} ({upw} units each) ; mean cycles per wave {tot / nw:.0f}")
 print(f"  ideal hidden layers: 2 x {3072 * upw // 16} v_pk_fma_f32 per stage; {27.6 * upw / 16:.1f} k per wave and step")
-for i in (0, 1, 3, 2, 4, 5, 6, 7):
+for i in (0, 1, 3, 2, 4, 5, 6, 8, 9, 7):
     print(f"  [{i}] {names[i]:62s} {s[i] / nw:10.0f} cyc/wave  {100 * s[i] / tot:5.1f} %")
