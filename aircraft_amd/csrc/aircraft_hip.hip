@@ -166,12 +166,15 @@ struct DeviceGuard {
 #endif
 template <int MODEL> struct HessN { static constexpr int value = (MODEL == AC_MODEL_POLY) ? AC_HESS_N_POLY : AC_HESS_N_OTHER; };
 
-// Models with an adjoint (default, linear, quadrotor, the MLP through its stage tensors): the reverse sweep in duals
-// (ac_hess_adj.hpp), one wave per direction group and 64 units.  The cubic fits keep the jet kernel.
+// The reverse sweep in duals (ac_hess_adj.hpp), one wave per direction group and 64 units; -DAC_HESS_JETS keeps the
+// second-order-jet kernel of rounds 1-3 (k_step_hess) as the A/B flavour.
 // directions per lane: two where the sweep fits the register file with them (no scratch); the MLP provider's extra state
 // (stage tensors, the 5 x 5 contraction) leaves room for one (AC_HESS_REV_N_NN: measured both)
 #ifndef AC_HESS_REV_N
 #define AC_HESS_REV_N 2
+#endif
+#ifndef AC_HESS_REV_N_POLY
+#define AC_HESS_REV_N_POLY 1
 #endif
 #ifndef AC_HESS_REV_N_NN
 #define AC_HESS_REV_N_NN 2
@@ -180,8 +183,8 @@ template <int MODEL>
 void launch_hess(ac_handle* h, hipStream_t st, const float* X, const float* U, float dt, const float* dt_per_unit,
                         const float* Lam, long n, long blk, float* Hout, int* grid_out) {
 #ifndef AC_HESS_JETS
-    if constexpr (MODEL != AC_MODEL_POLY) {
-        constexpr int NR = MODEL == AC_MODEL_NN ? AC_HESS_REV_N_NN : AC_HESS_REV_N;
+    {
+        constexpr int NR = MODEL == AC_MODEL_NN ? AC_HESS_REV_N_NN : (MODEL == AC_MODEL_POLY ? AC_HESS_REV_N_POLY : AC_HESS_REV_N);
         static_assert((16 / NR) % (kBlock / 64) == 0, "direction groups per workgroup");
         const dim3 grid((unsigned)((n + 63) / 64), (16 / NR) / (kBlock / 64));
         hipLaunchKernelGGL((k_step_hess_rev<MODEL, NR>), grid, kBlock, 0, st, h->dp, X, U, dt, dt_per_unit, Lam,

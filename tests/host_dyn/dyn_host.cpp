@@ -106,11 +106,19 @@ template <int MODEL, int N> void unit_adjoint(const DevParams& P, const float xv
 
 }  // namespace
 
-extern "C" int host_dyn_adjoint(const ac_params* p, const float* linear_W, int N, const float* X, const float* U, float dt,
-                                const float* Lam, long n, float* grad /*[21][n]*/, float* Hm /*[21][21][n]*/) {
+extern "C" int host_dyn_adjoint(const ac_params* p, const float* linear_W, const float* poly_coef, const float* poly_intercept, int N,
+                                const float* X, const float* U, float dt, const float* Lam, long n, float* grad /*[21][n]*/,
+                                float* Hm /*[21][21][n]*/) {
     DevParams P{};
     P.p = *p;
     if (linear_W) for (int i = 0; i < 36; ++i) P.linear_W[i] = linear_W[i];
+    alignas(64) static thread_local float tab[kPolyTabFloats];
+    if (poly_coef && poly_intercept) {
+        float gradt[6 * 4 * 15];
+        poly_gradient_tables(poly_coef, gradt);
+        poly_pack_tables(poly_coef, poly_intercept, gradt, tab);
+        P.poly_tab = tab;
+    }
     if (P.p.substeps > 1) return -1;
     for (long u = 0; u < n; ++u) {
         float xv[13], uv[7], lam[13], g[21], H[441];
@@ -120,6 +128,7 @@ extern "C" int host_dyn_adjoint(const ac_params* p, const float* linear_W, int N
 #define AC_CASE(M_, N_) if (!done && P.p.model_kind == M_ && N == N_) { unit_adjoint<M_, N_>(P, xv, uv, dt, lam, g, H); done = true; }
         AC_CASE(AC_MODEL_DEFAULT, 1) AC_CASE(AC_MODEL_DEFAULT, 2) AC_CASE(AC_MODEL_DEFAULT, 4)
         AC_CASE(AC_MODEL_LINEAR, 1) AC_CASE(AC_MODEL_LINEAR, 2) AC_CASE(AC_MODEL_QUAD, 2)
+        AC_CASE(AC_MODEL_POLY, 1) AC_CASE(AC_MODEL_POLY, 2)
 #undef AC_CASE
         if (!done) return -2;
         for (int i = 0; i < 21; ++i) grad[i * n + u] = g[i];

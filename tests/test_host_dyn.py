@@ -84,21 +84,22 @@ def _run_adjoint(ac, N, X, U, dt, lam):
     L = _lib()
     fp = C.POINTER(C.c_float)
     L.host_dyn_adjoint.restype = C.c_int
-    L.host_dyn_adjoint.argtypes = [C.c_void_p, fp, C.c_int, fp, fp, C.c_float, fp, C.c_long, fp, fp]
+    L.host_dyn_adjoint.argtypes = [C.c_void_p, fp, fp, fp, C.c_int, fp, fp, C.c_float, fp, C.c_long, fp, fp]
     n = X.shape[1]
     p = ac._param_struct()
     d = ac.coefficient_model.oracle_data() or {}
-    W = np.ascontiguousarray(d["W"], dtype=np.float32) if "W" in d else None
+    keep = [np.ascontiguousarray(d[k], dtype=np.float32) if k in d else None for k in ("W", "coef", "intercept")]
+    ptr = [a.ctypes.data_as(fp) if a is not None else None for a in keep]
     Xf, Uf, Lf = (np.ascontiguousarray(a, dtype=np.float32) for a in (X, U, lam))
     grad, Hm = np.zeros((21, n), dtype=np.float32), np.zeros((21, 21, n), dtype=np.float32)
-    rc = L.host_dyn_adjoint(C.byref(p), W.ctypes.data_as(fp) if W is not None else None, N, Xf.ctypes.data_as(fp),
+    rc = L.host_dyn_adjoint(C.byref(p), ptr[0], ptr[1], ptr[2], N, Xf.ctypes.data_as(fp),
                             Uf.ctypes.data_as(fp), dt, Lf.ctypes.data_as(fp), n, grad.ctypes.data_as(fp), Hm.ctypes.data_as(fp))
     assert rc == 0, rc
     return grad, Hm
 
 
 @pytest.mark.parametrize("model,normalise,stall,N", [("default", True, False, 2), ("default", False, True, 4), ("linear", True, True, 2),
-                                                     ("default", True, True, 1)])
+                                                     ("default", True, True, 1), ("poly", True, False, 2), ("poly", False, True, 1)])
 def test_reverse_sweep_gradient_and_hessian_on_host(model, normalise, stall, N):
     """ac_adjoint.hpp compiled for the host: the reverse sweep through the RK4 step in plain floats gives the gradient of
     lambda . F — checked against the oracle's EXACT Jacobians, [A | B | c]' lambda — and the same sweep in duals gives the
