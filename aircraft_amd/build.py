@@ -19,8 +19,11 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
 # register-spill scratch from 228 to 36 B/lane (HBM traffic 1.9x -> 1.1x of the algorithmic bytes) at +0.6 % speed
 # (same-box A/Bs).  Results are bit-identical: neither changes the order of any accumulation.
 UNIT_FLAGS = {
+    # (-mllvm -amdgpu-sched-strategy=max-ilp was measured on these three units: it takes the instructions that consume the result
+    # of the one or two before them from 158 of 689 to 12 in the default model's stage body, and the kernels run 2-6 % SLOWER:
+    # they are bound by vector-ALU throughput, not by dependent issue — DESIGN.md §6.2)
     "an_inst_sens_poly": ["-fno-slp-vectorize"],
-    "nn_inst_wt2_mfma_sens_w2": ["-fno-slp-vectorize"],  # (the same, for the small-net kernel at two waves per SIMD)
+    "nn_inst_wt2_mfma_sens_w2": ["-fno-slp-vectorize"],  # (the small-net kernel at two waves per SIMD)
     "nn_inst_wt8_mfma_sens": ["-DAC_CH=2", "-mllvm", "-slp-threshold=6"],
     "nn_inst_wt8_mfma_pair": ["-DAC_CH=2", "-mllvm", "-slp-threshold=6"],
 }

@@ -41,12 +41,27 @@ def run(name, ac, B, H, iters=10):
     t_roll = timeit(lambda: ms.rollout(x0, U, out=traj), max(2, iters // 2))
     k_roll = ac.last_launch()
     n = B * H
-    print(json.dumps({"case": name, "B": B, "H": H,
+    # SURVEY §8d contract figures: 1 172 B and 24 F_mlp + 30 000 flop per unit with sensitivities; the governing roofline is
+    # HBM without a network (25.6 flop/B is at the ridge) and fp32 compute with one
+    f_mlp = ac.coefficient_model.data.flops_forward() if getattr(ac.coefficient_model, "data", None) is not None else 0
+    flops = 24 * f_mlp + 30000
+    if f_mlp:
+        ach = flops * n / (t_sens * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "flops_per_unit": flops}
+    else:
+        ach = 1172 * n / (t_sens * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "bytes_per_unit": 1172,
+                "fp32_frac": flops * n / (t_sens * 1e-3) / 1e12 / 157.3}
+    print(json.dumps({"case": name, "B": B, "H": H, "roofline": roof,
                       "sens_steps_per_s": n / t_sens * 1e3, "sens_ms": t_sens, "sens_kernel": k_sens[0],
                       "fwd_steps_per_s": n / t_fwd * 1e3, "fwd_ms": t_fwd,
                       "rollout_steps_per_s": n / t_roll * 1e3, "rollout_ms": t_roll, "rollout_grid": k_roll[1]}), flush=True)
 
-which = sys.argv[1:] or ["cfg3", "cfg2", "cfg2_valu", "real", "poly", "default", "linear", "cfg5"]
+# usage: bench_modes.py [cases...]   or   bench_modes.py --model poly   (one model's line with its roofline object)
+args = sys.argv[1:]
+if "--model" in args:
+    args = [args[args.index("--model") + 1]]
+which = args or ["cfg3", "cfg2", "cfg2_valu", "real", "poly", "default", "linear", "cfg5"]
 if "cfg3" in which: run("cfg3 4x128 mfma", make_aircraft("nn", hidden=(128,) * 4), 4096, 50)
 if "cfg2" in which:
     run("cfg2 3x64 mfma B=256", make_aircraft("nn", hidden=(64,) * 3), 256, 50)
