@@ -390,8 +390,17 @@ struct AeroD { float vr[3], alpha, beta, qbar, w[3], da, de, dr; };
 //                           provider runs the whole network here from primal inputs, so that nothing but the
 //                           RK4 carry is live across the (register-hungry) network evaluation
 //   operator()(P, a, x, u, C)   turns the aerodynamic inputs (with tangents) into the six coefficients
-template <int MODEL> struct AnalyticCoeffs {
+// SHARED (cubic fits, the kernels whose four waves are the four direction groups of the SAME 64 units): the primal part of
+// linearise() — six fits with their gradients, 564 multiply-adds and four inverse trigonometric functions per stage — is the
+// same in all four waves.  Each wave evaluates a quarter of it and the quarters are exchanged through LDS (`xch`, kPolyXchFloats
+// floats, [2][34][64]: double-buffered, ONE workgroup barrier per call).  Same chains, same operations: bit-identical results.
+constexpr int kPolyXchRows = 34, kPolyXchFloats = 2 * kPolyXchRows * 64;
+template <int MODEL, bool SHARED = false> struct AnalyticCoeffs {
     static constexpr int kModel = MODEL;
+    static_assert(!SHARED || MODEL == AC_MODEL_POLY, "only the cubic fits are worth sharing");
+    float* xch = nullptr;  // SHARED: the workgroup's exchange buffer
+    int xg = 0;            // SHARED: this wave's quarter (wave-uniform)
+    int xph = 0;           // SHARED: call counter (which half of the buffer)
     template <class T> AC_DI void prefetch(const DevParams&, const T*, const float*) {}
     // First-order tangents, one direction at a time (state_derivative for duals, below): linearise() evaluates the model on
     // the primal and keeps its partial derivatives (closed forms; for the cubic fits value and gradient from the
@@ -411,40 +420,92 @@ template <int MODEL> struct AnalyticCoeffs {
             const float ux = v0 + eps;
             // effective angles (aircraft.py:189-233) with the coefficients of their differentials
             const float ye = v2 + arm * w[1], yl = v2 - b4 * w[0], yr = v2 + b4 * w[0];
-            const float alpha_e = atan2f(ye, ux), alpha_l = atan2f(yl, ux), alpha_r = atan2f(yr, ux);
             const float de_ = 1.0f / fmaf(ux, ux, ye * ye), dl_ = 1.0f / fmaf(ux, ux, yl * yl), dr_ = 1.0f / fmaf(ux, ux, yr * yr);
             const float vy = v1 - arm * w[2];
             const float nb = sqrtf(v0 * v0 + vy * vy + v2 * v2 + eps);
             const float tb = vy / nb;
-            const float beta_r = asinf(tb);
             const float gb = (1.0f / nb) / sqrtf(fmaf(-tb, tb, 1.0f));
             const float kb = gb * tb / nb;  // d beta_r = gb d vy - kb (v0 d v0 + vy d vy + v2 d v2)
             float val4[4], vale[1], valr[1], ge[1][4], gr[1][4];
-            {
-                const float f[4] = {a.alpha, a.beta, u[0], u[1]};
-                const int ks[4] = {0, 1, 2, 3};
-                poly_value_grad<4>(P, ks, f, val4, lin.g4);
-            }
-            {
-                const float f[4] = {alpha_e, a.beta, u[0], u[1]};
-                const int ks[1] = {4};
-                poly_value_grad<1>(P, ks, f, vale, ge);
-            }
-            {
-                const float f[4] = {a.alpha, beta_r, u[0], u[1]};
-                const int ks[1] = {5};
-                poly_value_grad<1>(P, ks, f, valr, gr);
+            float czr, czl;
+            const float hb = b4 * 0.5f;
+            if constexpr (!SHARED) {
+                const float alpha_e = atan2f(ye, ux), alpha_l = atan2f(yl, ux), alpha_r = atan2f(yr, ux);
+                const float beta_r = asinf(tb);
+                {
+                    const float f[4] = {a.alpha, a.beta, u[0], u[1]};
+                    const int ks[4] = {0, 1, 2, 3};
+                    poly_value_grad<4>(P, ks, f, val4, lin.g4);
+                }
+                {
+                    const float f[4] = {alpha_e, a.beta, u[0], u[1]};
+                    const int ks[1] = {4};
+                    poly_value_grad<1>(P, ks, f, vale, ge);
+                }
+                {
+                    const float f[4] = {a.alpha, beta_r, u[0], u[1]};
+                    const int ks[1] = {5};
+                    poly_value_grad<1>(P, ks, f, valr, gr);
+                }
+                // P_CZ(alpha_x, 0, 0, 0) and its slope
+                const PolyTab tab(P);
+                const float z0 = tab.intercept(2), z1 = tab.coef(2, 0), z2 = tab.coef(2, 4), z3 = tab.coef(2, 14);
+                czr = fmaf(fmaf(fmaf(z3, alpha_r, z2), alpha_r, z1), alpha_r, z0);
+                czl = fmaf(fmaf(fmaf(z3, alpha_l, z2), alpha_l, z1), alpha_l, z0);
+                lin.sr = hb * fmaf(fmaf(3.0f * z3, alpha_r, z2 + z2), alpha_r, z1);
+                lin.sl = -(hb * fmaf(fmaf(3.0f * z3, alpha_l, z2 + z2), alpha_l, z1));
+            } else {
+#ifndef AC_HOST_CHECK
+                // rows of the exchange buffer: 0..5 the values, 6 + 4 k + v the gradients, 30 / 31 cz and slope term of the left
+                // wing station, 32 / 33 of the right one
+                float* xb = xch + (xph & 1) * (kPolyXchRows * 64) + (threadIdx.x & 63);
+                ++xph;
+                if (xg < 2) {  // waves 0, 1: fits (0, 1), (2, 3) at (alpha, beta)
+                    const float f[4] = {a.alpha, a.beta, u[0], u[1]};
+                    const int ks[2] = {2 * xg, 2 * xg + 1};
+                    float v2[2], g2[2][4];
+                    poly_value_grad<2>(P, ks, f, v2, g2);
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) {
+                        xb[(2 * xg + o) * 64] = v2[o];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) xb[(6 + 4 * (2 * xg + o) + v) * 64] = g2[o][v];
+                    }
+                } else {  // wave 2: the elevator fit at alpha_e + the left wing station; wave 3: the rudder fit at beta_r + the right one
+                    const bool el = xg == 2;
+                    const float ang = el ? atan2f(ye, ux) : asinf(tb);
+                    const float f[4] = {el ? ang : a.alpha, el ? a.beta : ang, u[0], u[1]};
+                    const int ks[1] = {el ? 4 : 5};
+                    float v1[1], g1[1][4];
+                    poly_value_grad<1>(P, ks, f, v1, g1);
+                    xb[ks[0] * 64] = v1[0];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) xb[(6 + 4 * ks[0] + v) * 64] = g1[0][v];
+                    const float alpha_w = atan2f(el ? yl : yr, ux);
+                    const PolyTab tab(P);
+                    const float z0 = tab.intercept(2), z1 = tab.coef(2, 0), z2 = tab.coef(2, 4), z3 = tab.coef(2, 14);
+                    const float cz = fmaf(fmaf(fmaf(z3, alpha_w, z2), alpha_w, z1), alpha_w, z0);
+                    const float sw = hb * fmaf(fmaf(3.0f * z3, alpha_w, z2 + z2), alpha_w, z1);
+                    xb[(el ? 30 : 32) * 64] = cz;
+                    xb[(el ? 31 : 33) * 64] = el ? -sw : sw;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    val4[k] = xb[k * 64];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) lin.g4[k][v] = xb[(6 + 4 * k + v) * 64];
+                }
+                vale[0] = xb[4 * 64]; valr[0] = xb[5 * 64];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { ge[0][v] = xb[(22 + v) * 64]; gr[0][v] = xb[(26 + v) * 64]; }
+                czl = xb[30 * 64]; lin.sl = xb[31 * 64]; czr = xb[32 * 64]; lin.sr = xb[33 * 64];
+#else
+                czr = czl = 0.f;
+#endif
             }
 #pragma unroll
             for (int v = 0; v < 4; ++v) { lin.ge[v] = ge[0][v]; lin.gr[v] = gr[0][v]; }
-            // P_CZ(alpha_x, 0, 0, 0) and its slope
-            const PolyTab tab(P);
-            const float z0 = tab.intercept(2), z1 = tab.coef(2, 0), z2 = tab.coef(2, 4), z3 = tab.coef(2, 14);
-            const float czr = fmaf(fmaf(fmaf(z3, alpha_r, z2), alpha_r, z1), alpha_r, z0);
-            const float czl = fmaf(fmaf(fmaf(z3, alpha_l, z2), alpha_l, z1), alpha_l, z0);
-            const float hb = b4 * 0.5f;
-            lin.sr = hb * fmaf(fmaf(3.0f * z3, alpha_r, z2 + z2), alpha_r, z1);
-            lin.sl = -(hb * fmaf(fmaf(3.0f * z3, alpha_l, z2 + z2), alpha_l, z1));
 #pragma unroll
             for (int k = 0; k < 4; ++k) C[k] = val4[k];
             C[3] = fmaf(hb, czr - czl, C[3]);

@@ -370,7 +370,13 @@ __global__ __launch_bounds__(kBlock, kSensWavesPerSimd) void k_deriv_sens(const 
     load_rows<13>(X, ua, xv);
     load_rows<7>(U, ua, uv);
     Dual<kAnN> k[13];
-    AnalyticCoeffs<MODEL> coeffs;
+    constexpr bool kShared = MODEL == AC_MODEL_POLY;  // the four waves split the primal part of the cubic fits (AnalyticCoeffs)
+    AnalyticCoeffs<MODEL, kShared> coeffs;
+    if constexpr (kShared) {
+        __shared__ float poly_xch[kPolyXchFloats];
+        coeffs.xch = poly_xch;
+        coeffs.xg = g;
+    }
     deriv_seeded<kAnN>(P, coeffs, g, xv, uv, k);
     if (live) deriv_store<kAnN, MODEL == AC_MODEL_QUAD>(P, X, unit, g, ua, k, Xdot, Fx, Fu);
 }
@@ -647,7 +653,13 @@ __global__ __launch_bounds__(kBlock, kSensWavesPerSimd) void k_step_sens(const D
     load_rows<7>(U, ua, uv);
     const float hv = dt_per_unit ? dt_per_unit[unit] : dt;
     Dual<kAnN> x[13];
-    AnalyticCoeffs<MODEL> coeffs;
+    constexpr bool kShared = MODEL == AC_MODEL_POLY && !SUBSTEPPED;  // (see k_deriv_sens)
+    AnalyticCoeffs<MODEL, kShared> coeffs;
+    if constexpr (kShared) {
+        __shared__ float poly_xch[kPolyXchFloats];
+        coeffs.xch = poly_xch;
+        coeffs.xg = g;
+    }
     static_assert(kAnN == 4, "LdsAcc4");
     __shared__ float4 acc_words[13 * kBlock];  // 53 KB: two workgroups per CU
     LdsAcc4 acc(&acc_words[threadIdx.x], kBlock);

@@ -19,7 +19,7 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU 
   tag=$(echo $grp | tr ' ' '_' | cut -c1-30)
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/r4_pmc_final/$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/r4_pmc_final_$tag.json 2> gpurun_out/r4_pmc_final_$tag.err || echo "pass $tag failed"
 done
-python tools/pmc_traffic.py 3 r4_pmc_final || true
+python tools/pmc_traffic.py 4 r4_pmc_final || true
 # the headline line again, now carrying this build's measured traffic
 python bench.py > gpurun_out/r4_bench_final.json 2> gpurun_out/r4_bench_final.err || echo "bench rc=$?"
 cat gpurun_out/r4_bench_final.json
