@@ -7,28 +7,50 @@
 namespace ac {
 
 // MLP surrogate through the stage tensors (y, J, T) of k_nn_stage_tensors (layout: HessTensorCoeffs, ac_hess.hpp)
-// Optional LDS tile [126][64] through which the four waves of a workgroup (four direction groups of the SAME 64 units) can
-// share the tensors of the current stage, filled cooperatively at set_stage().  MEASURED AND NOT USED (the kernel passes no
-// tile): a quarter of the global loads, but the four waves then meet at 14 barriers per task with every load burst fully
-// exposed — 204 800 units of the 4 x 128 net: 15.1 ms against 14.0 (one direction per lane), 14.1 against 13.7 (two).
-struct AdjTensorCoeffs : HessTensorCoeffs {
-    const float* tp;  // row 0 of the current stage for this lane's unit
-    long ts;          // distance between rows
-    float* tile;      // LDS [126][64], or nullptr: read global memory directly
-    int loaded;
-    AC_DI AdjTensorCoeffs(const float* tensors, const UnitAddr& ua, float* lds_tile = nullptr)
-        : HessTensorCoeffs(tensors, ua), tp(base), ts(ua.blk), tile(lds_tile), loaded(-1) {}
+// LDS tile: the four waves of a workgroup are four direction groups of the SAME 64 units and read the same 126 rows of every
+// stage.  Filled synchronously (cooperative loads, two barriers per stage) the tile was SLOWER than plain global loads — every
+// load burst fully exposed: 15.1 ms against 14.0 per 204 800 units of the 4 x 128 net.  Here it is filled by LDS-DMA one stage
+// AHEAD: two buffers [2][126][64]; the stage sequence of rk4_vjp is 0 1 2 3 | 3 2 1 0, stage s lives in buffer s & 1, and the
+// rows of the next distinct stage are requested right after the barrier that opens the current one (the buffer they land in
+// was last read in the step before: every wave is past it).  A wave requests rows wave, wave + 4, ...: one
+// global_load_lds_dword per row (64 lanes x 4 B = the row), no vector register involved.
+constexpr int kAdjTileFloats = 2 * 126 * 64;
+template <bool TILE> struct AdjTensorCoeffsT : HessTensorCoeffs {
+    const float* tp;  // !TILE: row 0 of the current stage for this lane's unit in global memory, rows `blk` apart
+    float* tile;      // TILE: LDS [2][126][64]
+    int cur;          // TILE: float offset of this lane's column of the current stage's buffer
+    int step;         // calls of set_stage so far
+    AC_DI AdjTensorCoeffsT(const float* tensors, const UnitAddr& ua, float* lds_tile = nullptr)
+        : HessTensorCoeffs(tensors, ua), tp(base), tile(lds_tile), cur(0), step(0) {}
+    // row r of the current stage
+    AC_DI float row(int r) const {
+        if constexpr (TILE) return tile[cur + r * 64];
+        else return tp[(long)r * blk];
+    }
+#ifndef AC_HOST_CHECK
+    AC_DI void request(int s) const {
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        constexpr int nw = kBlock / 64;
+        const float* src = base + (long)s * 126 * blk;  // this lane's unit
+        float* dst = tile + (s & 1) * (126 * 64);
+        for (int r = wave; r < 126; r += nw)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)r * blk),
+                                             (__attribute__((address_space(3))) void*)(dst + r * 64), 4, 0, 0);
+    }
+#endif
     AC_DI void set_stage(int s) {
         stage = s;
-        if (!tile) { tp = base + (long)s * 126 * blk; ts = blk; return; }
-        if (loaded == s) return;  // (the reverse sweep starts at the stage the forward sweep ended with)
-        loaded = s;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-        __syncthreads();  // every wave has finished reading the previous stage's tile
-        const float* src = base + (long)s * 126 * blk;
-        for (int idx = wave; idx < 126; idx += nw) tile[idx * 64 + lane] = src[(long)idx * blk];
-        __syncthreads();
-        tp = tile + lane; ts = 64;
+        if constexpr (!TILE) { tp = base + (long)s * 126 * blk; return; }
+#ifndef AC_HOST_CHECK
+        const int i = step++;
+        if (i == 4) return;  // the reverse sweep starts on the stage the forward sweep ended with
+        if (i == 0) request(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave's rows of stage s have landed; every wave is done with the other buffer
+        const int nxt = i < 3 ? s + 1 : s - 1;
+        if (nxt >= 0) request(nxt);
+        cur = (s & 1) * (126 * 64) + (int)(threadIdx.x & 63);
+#endif
     }
     // value: the second-order Taylor model of the net around the stage's primal inputs, in first-order duals:
     //   C_k = os_k (y_k + J_k . dz) + mean_k  with dz the tangent parts only (the primal IS the expansion point)
@@ -38,12 +60,12 @@ struct AdjTensorCoeffs : HessTensorCoeffs {
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const float os = P.mlp_out_std[k];
-            C[k].v = fmaf(tp[(long)k * ts], os, P.mlp_out_mean[k]);
+            C[k].v = fmaf(row(k), os, P.mlp_out_mean[k]);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 float s = 0.f;
 #pragma unroll
-                for (int j = 0; j < 5; ++j) s = fmaf(tp[(long)(6 + k * 5 + j) * ts] * P.mlp_jscale[k][j], in[j]->d[i], s);
+                for (int j = 0; j < 5; ++j) s = fmaf(row(6 + k * 5 + j) * P.mlp_jscale[k][j], in[j]->d[i], s);
                 C[k].d[i] = s;
             }
         }
@@ -51,7 +73,7 @@ struct AdjTensorCoeffs : HessTensorCoeffs {
     }
     AC_DI void operator()(const DevParams& P, const AeroPre<float>&, const float*, const float u[7], float C[6]) const {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) C[k] = fmaf(tp[(long)k * ts], P.mlp_out_std[k], P.mlp_out_mean[k]);
+        for (int k = 0; k < 6; ++k) C[k] = fmaf(row(k), P.mlp_out_std[k], P.mlp_out_mean[k]);
         C[5] += (-0.1f * 6.0f * kDeg) * u[2];
     }
     // adjoint: in_bar_j = sum_k (os_k / std_j) Cbar_k J_kj(z), with J_kj(z) = J_kj + sum_q T_kjq dz_q in duals
@@ -76,7 +98,7 @@ struct AdjTensorCoeffs : HessTensorCoeffs {
             for (int p = 0; p < 5; ++p)
 #pragma unroll
                 for (int q = p; q < 5; ++q) {
-                    const float tpq = tp[(long)(36 + k * 15 + (p * 5 - p * (p - 1) / 2 + (q - p))) * ts];
+                    const float tpq = row(36 + k * 15 + (p * 5 - p * (p - 1) / 2 + (q - p)));
                     S[p][q] = fmaf(ck, tpq, S[p][q]);
                 }
         }
@@ -90,7 +112,7 @@ struct AdjTensorCoeffs : HessTensorCoeffs {
             ib[j] = Dual<N>(0.f);
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                const float Jkj = tp[(long)(6 + k * 5 + j) * ts] * P.mlp_out_std[k];
+                const float Jkj = row(6 + k * 5 + j) * P.mlp_out_std[k];
                 ib[j].v = fmaf(Jkj, Cb[k].v, ib[j].v);
 #pragma unroll
                 for (int i = 0; i < N; ++i) ib[j].d[i] = fmaf(Jkj, Cb[k].d[i], ib[j].d[i]);
@@ -113,7 +135,7 @@ struct AdjTensorCoeffs : HessTensorCoeffs {
         for (int j = 0; j < 5; ++j) {
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) s = fmaf(tp[(long)(6 + k * 5 + j) * ts] * P.mlp_out_std[k], Cb[k], s);
+            for (int k = 0; k < 6; ++k) s = fmaf(row(6 + k * 5 + j) * P.mlp_out_std[k], Cb[k], s);
             ib[j] = s / P.mlp_in_std[j];
         }
         ab.qbar += ib[0]; ab.alpha += ib[1]; ab.beta += ib[2];
@@ -122,7 +144,8 @@ struct AdjTensorCoeffs : HessTensorCoeffs {
     }
 };
 template <int MODEL> struct AdjProvider { typedef AdjAnalyticCoeffs<MODEL> type; };
-template <> struct AdjProvider<AC_MODEL_NN> { typedef AdjTensorCoeffs type; };
+template <> struct AdjProvider<AC_MODEL_NN> { typedef AdjTensorCoeffsT<false> type; };
+typedef AdjTensorCoeffsT<false> AdjTensorCoeffs;
 
 
 
@@ -170,7 +193,14 @@ __global__ __launch_bounds__(kBlock) void k_step_hess_rev(const DevParams P, con
     T xo[13], gx[13], gu[7], gh;
     __shared__ float stage_words[30 * (N + 1) * kBlock];  // N = 2: 92 KB (one workgroup per CU: the kernel owns the register file anyway)
     auto make_coeffs = [&]() {
-        if constexpr (MODEL == AC_MODEL_NN) return AdjTensorCoeffs(stage_tensors, ua, nullptr);
+        if constexpr (MODEL == AC_MODEL_NN) {
+#ifdef AC_HESS_NO_TILE  // (A/B flavour: the stage tensors by plain global loads)
+            return AdjTensorCoeffsT<false>(stage_tensors, ua, nullptr);
+#else
+            __shared__ float tensor_tile[kAdjTileFloats];
+            return AdjTensorCoeffsT<true>(stage_tensors, ua, tensor_tile);
+#endif
+        }
         else return typename AdjProvider<MODEL>::type(stage_tensors, ua);
     };
     auto coeffs = make_coeffs();
