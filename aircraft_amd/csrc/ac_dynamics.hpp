@@ -183,10 +183,11 @@ template <int N> AC_DI void aero_pre(const DevParams& P, const Dual<N> x[13], Ae
     const float t = v1 / V;
     a.beta.v = asinf(t);
     a.qbar.v = (0.5f * 1.225f) * vv;
-    const float den = 1.0f / fmaf(ux, ux, v2 * v2);
+    const float den = AC_RCP(fmaf(ux, ux, v2 * v2));
     const float ca_y = ux * den, ca_x = -(v2 * den);            // d alpha = ca_y d v2 + ca_x d v0
-    const float gV = 0.5f / V;                                   // d V = gV d vv
-    const float gb = (1.0f / V) / sqrtf(fmaf(-t, t, 1.0f));      // d beta = gb (d v1 - t d V)
+    const float rV = AC_RCP(V);
+    const float gV = 0.5f * rV;                                  // d V = gV d vv
+    const float gb = rV * AC_RSQ(fmaf(-t, t, 1.0f));             // d beta = gb (d v1 - t d V)
     const float gbt = -(gb * t);
     const float w0 = v0 + v0, w1 = v1 + v1, w2 = v2 + v2;
 #pragma unroll
@@ -420,18 +421,19 @@ template <int MODEL, bool SHARED = false> struct AnalyticCoeffs {
             const float ux = v0 + eps;
             // effective angles (aircraft.py:189-233) with the coefficients of their differentials
             const float ye = v2 + arm * w[1], yl = v2 - b4 * w[0], yr = v2 + b4 * w[0];
-            const float de_ = 1.0f / fmaf(ux, ux, ye * ye), dl_ = 1.0f / fmaf(ux, ux, yl * yl), dr_ = 1.0f / fmaf(ux, ux, yr * yr);
+            const float de_ = AC_RCP(fmaf(ux, ux, ye * ye)), dl_ = AC_RCP(fmaf(ux, ux, yl * yl)), dr_ = AC_RCP(fmaf(ux, ux, yr * yr));
             const float vy = v1 - arm * w[2];
-            const float nb = sqrtf(v0 * v0 + vy * vy + v2 * v2 + eps);
-            const float tb = vy / nb;
-            const float gb = (1.0f / nb) / sqrtf(fmaf(-tb, tb, 1.0f));
-            const float kb = gb * tb / nb;  // d beta_r = gb d vy - kb (v0 d v0 + vy d vy + v2 d v2)
+            const float nb2 = v0 * v0 + vy * vy + v2 * v2 + eps;
+            auto sin_beta_r = [&]() { return vy / sqrtf(nb2); };  // the primal argument of asin: the forward kernels' expression
+            const float rnb = AC_RSQ(nb2), tbt = vy * rnb;
+            const float gb = rnb * AC_RSQ(fmaf(-tbt, tbt, 1.0f));
+            const float kb = gb * tbt * rnb;  // d beta_r = gb d vy - kb (v0 d v0 + vy d vy + v2 d v2)
             float val4[4], vale[1], valr[1], ge[1][4], gr[1][4];
             float czr, czl;
             const float hb = b4 * 0.5f;
             if constexpr (!SHARED) {
                 const float alpha_e = atan2f(ye, ux), alpha_l = atan2f(yl, ux), alpha_r = atan2f(yr, ux);
-                const float beta_r = asinf(tb);
+                const float beta_r = asinf(sin_beta_r());
                 {
                     const float f[4] = {a.alpha, a.beta, u[0], u[1]};
                     const int ks[4] = {0, 1, 2, 3};
@@ -473,7 +475,7 @@ template <int MODEL, bool SHARED = false> struct AnalyticCoeffs {
                     }
                 } else {  // wave 2: the elevator fit at alpha_e + the left wing station; wave 3: the rudder fit at beta_r + the right one
                     const bool el = xg == 2;
-                    const float ang = el ? atan2f(ye, ux) : asinf(tb);
+                    const float ang = el ? atan2f(ye, ux) : asinf(sin_beta_r());
                     const float f[4] = {el ? ang : a.alpha, el ? a.beta : ang, u[0], u[1]};
                     const int ks[1] = {el ? 4 : 5};
                     float v1[1], g1[1][4];
@@ -613,12 +615,14 @@ template <class T> struct AeroPost {
     T C[6], F[3], M[3];
 };
 
+// stall: the factors (sa, sb) formed by the caller with the expressions below (state_derivative for duals shares them with the
+// coefficients of its tangents), or nullptr
 template <class T>
-AC_DI void aero_post(const DevParams& P, const AeroPre<T>& a, const T u[7], T C[6], AeroPost<T>& o) {
+AC_DI void aero_post(const DevParams& P, const AeroPre<T>& a, const T u[7], T C[6], AeroPost<T>& o, const T* stall = nullptr) {
     if (P.p.stall_scaling) {  // uniform branch; dynamics/aircraft.py:280-294
         const float lim = 30.0f * kDeg, steep = 10.0f;
-        const T sa = 1.0f / (1.0f + m_exp(steep * (m_fabs(a.alpha) - lim)));
-        const T sb = 1.0f / (1.0f + m_exp(steep * (m_fabs(a.beta) - lim)));
+        const T sa = stall ? stall[0] : 1.0f / (1.0f + m_exp(steep * (m_fabs(a.alpha) - lim)));
+        const T sb = stall ? stall[1] : 1.0f / (1.0f + m_exp(steep * (m_fabs(a.beta) - lim)));
         C[2] = C[2] * sa; C[2] = C[2] * sb; C[4] = C[4] * sa;
     }
     C[0] = C[0] + (-0.1f) * u[6];
@@ -841,17 +845,19 @@ AC_DI void state_derivative(const DevParams& P, Coeffs& coeffs, const Dual<N> x[
 #endif
         // stall factors (dynamics/aircraft.py:280-294) as coefficients of (dC, d alpha, d beta)
         float s2 = 1.f, k2a = 0.f, k2b = 0.f, s4 = 1.f, k4a = 0.f;
+        float stall[2] = {1.f, 1.f};
         if (P.p.stall_scaling) {
             const float lim = 30.0f * kDeg, steep = 10.0f;
-            const float ea = expf(steep * (fabsf(a.alpha) - lim)), eb = expf(steep * (fabsf(a.beta) - lim));
-            const float sa = 1.0f / (1.0f + ea), sb = 1.0f / (1.0f + eb);
+            const float ea = m_exp(steep * (m_fabs(a.alpha) - lim)), eb = m_exp(steep * (m_fabs(a.beta) - lim));
+            const float sa = 1.0f / (1.0f + ea), sb = 1.0f / (1.0f + eb);  // (aero_post's expressions: it takes them from here)
             const float dsa = -(sa * sa) * ea * (a.alpha < 0.f ? -steep : steep);
             const float dsb = -(sb * sb) * eb * (a.beta < 0.f ? -steep : steep);
             s2 = sa * sb; s4 = sa;
             k2a = C[2] * sb * dsa; k2b = C[2] * sa * dsb; k4a = C[4] * dsa;
+            stall[0] = sa; stall[1] = sb;
         }
         AeroPost<float> o;
-        aero_post(P, a, uv, C, o);  // (applies stall and flaps to C)
+        aero_post(P, a, uv, C, o, stall);  // (applies stall and flaps to C)
         float xdv[13];
         rigid_body(P, xv, o, xdv);
 #pragma unroll
@@ -874,11 +880,12 @@ AC_DI void state_derivative(const DevParams& P, Coeffs& coeffs, const Dual<N> x[
             const float r2[3] = {r.x + r.x, r.y + r.y, r.z + r.z};
             const float v0 = a.vr[0], v1 = a.vr[1], v2 = a.vr[2];
             const float ux = v0 + eps;
-            const float den = 1.0f / fmaf(ux, ux, v2 * v2);
+            const float den = AC_RCP(fmaf(ux, ux, v2 * v2));
             const float ca_y = ux * den, ca_x = -(v2 * den);        // d alpha = ca_y d v2 + ca_x d v0
-            const float tb = v1 / a.V;
-            const float gb = (1.0f / a.V) / sqrtf(fmaf(-tb, tb, 1.0f));
-            const float gbv = -(gb * tb) * (0.5f / a.V);            // d beta = gb d v1 + gbv d(v.v)
+            const float rV = AC_RCP(a.V);
+            const float tb = v1 * rV;
+            const float gb = rV * AC_RSQ(fmaf(-tb, tb, 1.0f));
+            const float gbv = -(gb * tb) * (0.5f * rV);             // d beta = gb d v1 + gbv d(v.v)
             const float w0 = v0 + v0, w1 = v1 + v1, w2 = v2 + v2;   // d(v.v) = 2 v . dv
             auto aero_d = [&](int j, AeroD& d) {
                 const float dv0 = x[3].d[j], dv1 = x[4].d[j], dv2 = x[5].d[j];

@@ -16,7 +16,14 @@
 #define AC_OPAQUE_S(x) ((void)0)
 #define AC_SCHED_FENCE() ((void)0)
 #define AC_CONSTANT
+#define AC_RCP(x) (1.0f / (x))
+#define AC_RSQ(x) (1.0f / sqrtf(x))
 #else
+// 1-ulp reciprocal / reciprocal square root (v_rcp_f32, v_rsq_f32: one instruction where an IEEE division or square root
+// is about ten).  ONLY for coefficients of tangents (Jacobian entries, bar 1e-5): every primal value keeps the forward
+// kernels' IEEE expressions.
+#define AC_RCP(x) __builtin_amdgcn_rcpf(x)
+#define AC_RSQ(x) __builtin_amdgcn_rsqf(x)
 // the same for a wave-uniform value (a pointer the loads behind it must not be hoisted past)
 #define AC_OPAQUE_S(x) asm volatile("" : "+s"(x))
 // constant address space: a uniform address in it is always read with scalar loads
