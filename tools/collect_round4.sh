@@ -20,3 +20,6 @@ cp $G/r4_smi_clocks.txt $P/r04_smi_clocks_power.txt
 [ -f $G/r4_kernel_stats_hess.csv ] && cp $G/r4_kernel_stats_hess.csv $P/r04_kernel_stats_hess.csv
 [ -f $G/r4_analytic_pmc_after.json ] && cp $G/r4_analytic_pmc_after.json $P/r04_analytic_pmc_after.json
 ls $P | grep r04
+[ -f $G/r4_analytic_after.txt ] && cp $G/r4_analytic_after.txt $P/r04_analytic_after.txt
+[ -f $G/r4_hess_pmc.txt ] && cp $G/r4_hess_pmc.txt $P/r04_hess_pmc.txt
+ls $P | grep -c r04
