@@ -310,7 +310,10 @@ AC_DI void sens_update(const DevParams& P, Coeffs& coeffs, int g, int col, const
 // the structured tangents (ac_dynamics.hpp) keep four directions within 256 registers = two waves per SIMD, which is
 // what lets the SIMD issue a vector instruction every ~2 cycles instead of every 4.
 template <int MODEL> struct AnalyticSensN { static constexpr int value = 4; };
-constexpr int kSensWavesPerSimd = 2;
+#ifndef AC_SENS_WPS
+#define AC_SENS_WPS 2
+#endif
+constexpr int kSensWavesPerSimd = AC_SENS_WPS;
 // ---- x_dot = f(x, u) with its Jacobians (the implicit defect row and the Baumgarte row differentiate f, not the step:
 // control/base.py:282-304; the LQR wrapper: dynamics/base.py:51-52) -------------------------------------------------
 // One evaluation of f seeded like the first RK4 stage: k[i].d[j] = df_i / d(direction N g + j).

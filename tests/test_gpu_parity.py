@@ -140,6 +140,30 @@ def test_step_sens(gpu, model):
     assert not Bm.cpu().numpy()[:, 3:6, :].any()
 
 
+@pytest.mark.parametrize("model", ["poly", "default", "linear", "real"])
+def test_step_sens_small_batches_and_shard_invariance(gpu, model):
+    """The sensitivity kernels of the analytic models exchange the primal part of the cubic fits between the four waves of
+    a workgroup behind a barrier, with the lanes past the batch clamped to its last unit: batches below, at and just past
+    a wave's 64 units against the oracle, and the same units evaluated in two launches must come out bit-identical."""
+    import torch
+    ac = build(model, normalise=True)
+    oracle = make_oracle(ac)
+    X, U = synthetic_units(130, seed=29, flaps=True)
+    Xr, Ar, Br, cr = oracle.step_sens(X, U, 0.01)
+    full = ac.step_sens(dev(X, gpu), dev(U, gpu), 0.01)
+    for n in (1, 3, 63, 64, 65, 130):
+        Xn, A, Bm, c = ac.step_sens(dev(X[:, :n], gpu), dev(U[:, :n], gpu), 0.01)
+        assert block_rel_err(Xn.cpu().numpy(), Xr[:, :n]) < STATE_TOL
+        assert_sens(f"step_sens_small[{model}-{n}]", {"A": A, "B": Bm, "c": c},
+                    {"A": Ar[..., :n], "B": Br[..., :n], "c": cr[..., :n]})
+        for got, ref in zip((Xn, A, Bm, c), full):
+            assert torch.equal(got, ref[..., :n])
+    # second half on its own: other workgroups, other lanes
+    Xn, A, Bm, c = ac.step_sens(dev(X[:, 67:], gpu), dev(U[:, 67:], gpu), 0.01)
+    for got, ref in zip((Xn, A, Bm, c), full):
+        assert torch.equal(got, ref[..., 67:])
+
+
 @pytest.mark.parametrize("model", ["default", "real"])
 def test_step_sens_unnormalised_and_stall(gpu, model):
     ac = build(model, normalise=False, stall_scaling=True)
