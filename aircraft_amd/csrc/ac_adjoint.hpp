@@ -31,6 +31,80 @@ template <class T> AC_DI T zero_like(const T&) { return T(0.f); }
 template <class T> struct AeroBar { T qbar, alpha, beta, vr[3]; };  // (vr: the cubic fits' effective angles read the relative velocity itself)
 
 // ---- adjoints of the coefficient models ------------------------------------------------------------------------------------
+// Adjoint of the cubic-fit model given `grad(k, f, g)`: the gradient of fit k at the point f, in T arithmetic.
+template <class T, class G>
+AC_DI void poly_vjp(const DevParams& P, const AeroPre<T>& a, const T x[13], const T u[7], const T Cb[6], AeroBar<T>& ab, T wb[3],
+                    T ub[7], G&& grad) {
+    // PolynomialModel (coefficient_models.py:106-133) with the effective angles of aircraft.py:189-233:
+    //   C_0..3 = P_0..3(alpha, beta, da, de),  C_3 += b/8 (P_CZ(alpha_r) - P_CZ(alpha_l)),
+    //   C_4 = P_4(alpha_e, beta, da, de),  C_5 = P_5(alpha, beta_r, da, de) + 0.01 * 6 deg * dr
+    const T* w = &x[10];
+    const float eps = P.p.epsilon, arm = P.p.rudder_moment_arm, b4 = P.p.b * 0.25f;
+    const T ux = a.vr[0] + eps;
+    const T ye = a.vr[2] + arm * w[1], yl = a.vr[2] - b4 * w[0], yr = a.vr[2] + b4 * w[0];
+    const T alpha_e = m_atan2(ye, ux), alpha_l = m_atan2(yl, ux), alpha_r = m_atan2(yr, ux);
+    const T vy = a.vr[1] - arm * w[2];
+    const T nb = m_sqrt(a.vr[0] * a.vr[0] + vy * vy + a.vr[2] * a.vr[2] + eps);
+    const T tb = vy / nb;
+    const T beta_r = m_asin(tb);
+    const PolyTab tab(P);
+    T fb_main[4] = {T(0.f), T(0.f), T(0.f), T(0.f)};  // adjoints of (alpha, beta, da, de) at the main point
+    const T fm[4] = {a.alpha, a.beta, u[0], u[1]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        T g[4];
+        grad(k, fm, g);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) fb_main[v] = fb_main[v] + Cb[k] * g[v];
+    }
+    T aeb, brb;  // adjoints of alpha_e, beta_r
+    {
+        const T fe[4] = {alpha_e, a.beta, u[0], u[1]};
+        T g[4];
+        grad(4, fe, g);
+        aeb = Cb[4] * g[0];
+        fb_main[1] = fb_main[1] + Cb[4] * g[1]; fb_main[2] = fb_main[2] + Cb[4] * g[2]; fb_main[3] = fb_main[3] + Cb[4] * g[3];
+    }
+    {
+        const T fr[4] = {a.alpha, beta_r, u[0], u[1]};
+        T g[4];
+        grad(5, fr, g);
+        fb_main[0] = fb_main[0] + Cb[5] * g[0];
+        brb = Cb[5] * g[1];
+        fb_main[2] = fb_main[2] + Cb[5] * g[2]; fb_main[3] = fb_main[3] + Cb[5] * g[3];
+    }
+    ab.alpha = ab.alpha + fb_main[0]; ab.beta = ab.beta + fb_main[1];
+    ub[0] = ub[0] + fb_main[2]; ub[1] = ub[1] + fb_main[3];
+    ub[2] = ub[2] + (0.01f * 6.0f * kDeg) * Cb[5];
+    // P_CZ(alpha_x, 0, 0, 0) = z0 + z1 a + z2 a^2 + z3 a^3
+    const float z1 = tab.coef(2, 0), z2 = tab.coef(2, 4), z3 = tab.coef(2, 14);
+    const float hb = b4 * 0.5f;
+    const T arb = (hb * Cb[3]) * (z1 + (2.0f * z2) * alpha_r + (3.0f * z3) * (alpha_r * alpha_r));
+    const T alb = -((hb * Cb[3]) * (z1 + (2.0f * z2) * alpha_l + (3.0f * z3) * (alpha_l * alpha_l)));
+    // the three atan2(y_x, ux)
+    T uxb = T(0.f);
+    auto atan2_bar = [&](const T& y, const T& bar, T& yb) {
+        const T iden = 1.0f / (ux * ux + y * y);
+        yb = bar * ux * iden;
+        uxb = uxb - bar * y * iden;
+    };
+    T yeb, ylb, yrb;
+    atan2_bar(ye, aeb, yeb); atan2_bar(yl, alb, ylb); atan2_bar(yr, arb, yrb);
+    ab.vr[0] = ab.vr[0] + uxb;
+    ab.vr[2] = ab.vr[2] + yeb + ylb + yrb;
+    wb[1] = wb[1] + arm * yeb;
+    wb[0] = wb[0] + b4 * (yrb - ylb);
+    // beta_r = asin(vy / |(vr0, vy, vr2)|_eps)
+    const T tbar = brb / m_sqrt(1.0f - tb * tb);
+    T vyb = tbar / nb;
+    const T sb2 = (-(tbar * tb) / nb) * (0.5f / nb);   // adjoint of the sum of squares
+    ab.vr[0] = ab.vr[0] + 2.0f * a.vr[0] * sb2;
+    vyb = vyb + 2.0f * vy * sb2;
+    ab.vr[2] = ab.vr[2] + 2.0f * a.vr[2] * sb2;
+    ab.vr[1] = ab.vr[1] + vyb;
+    wb[2] = wb[2] - arm * vyb;
+}
+
 template <int MODEL> struct AdjAnalyticCoeffs : AnalyticCoeffs<MODEL> {
     static constexpr bool kFusedTangent = false;  // (the reverse sweep evaluates f through the generic operator forms)
     AC_DI AdjAnalyticCoeffs() {}
@@ -51,20 +125,8 @@ template <int MODEL> struct AdjAnalyticCoeffs : AnalyticCoeffs<MODEL> {
             }
             ub[2] = ub[2] + (-0.1f * 6.0f * kDeg) * Cb[5];
         } else if constexpr (MODEL == AC_MODEL_POLY) {
-            // PolynomialModel (coefficient_models.py:106-133) with the effective angles of aircraft.py:189-233:
-            //   C_0..3 = P_0..3(alpha, beta, da, de),  C_3 += b/8 (P_CZ(alpha_r) - P_CZ(alpha_l)),
-            //   C_4 = P_4(alpha_e, beta, da, de),  C_5 = P_5(alpha, beta_r, da, de) + 0.01 * 6 deg * dr
-            const T* w = &x[10];
-            const float eps = P.p.epsilon, arm = P.p.rudder_moment_arm, b4 = P.p.b * 0.25f;
-            const T ux = a.vr[0] + eps;
-            const T ye = a.vr[2] + arm * w[1], yl = a.vr[2] - b4 * w[0], yr = a.vr[2] + b4 * w[0];
-            const T alpha_e = m_atan2(ye, ux), alpha_l = m_atan2(yl, ux), alpha_r = m_atan2(yr, ux);
-            const T vy = a.vr[1] - arm * w[2];
-            const T nb = m_sqrt(a.vr[0] * a.vr[0] + vy * vy + a.vr[2] * a.vr[2] + eps);
-            const T tb = vy / nb;
-            const T beta_r = m_asin(tb);
-            const PolyTab tab(P);
             // gradients of the fits in T arithmetic (the quadratic tables of DevParams::poly_tab)
+            const PolyTab tab(P);
             auto grad = [&](int k, const T f[4], T g[4]) {
                 T m2[10];
                 int t = 0;
@@ -82,61 +144,7 @@ template <int MODEL> struct AdjAnalyticCoeffs : AnalyticCoeffs<MODEL> {
                     g[v] = ga;
                 }
             };
-            T fb_main[4] = {T(0.f), T(0.f), T(0.f), T(0.f)};  // adjoints of (alpha, beta, da, de) at the main point
-            const T fm[4] = {a.alpha, a.beta, u[0], u[1]};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                T g[4];
-                grad(k, fm, g);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) fb_main[v] = fb_main[v] + Cb[k] * g[v];
-            }
-            T aeb, brb;  // adjoints of alpha_e, beta_r
-            {
-                const T fe[4] = {alpha_e, a.beta, u[0], u[1]};
-                T g[4];
-                grad(4, fe, g);
-                aeb = Cb[4] * g[0];
-                fb_main[1] = fb_main[1] + Cb[4] * g[1]; fb_main[2] = fb_main[2] + Cb[4] * g[2]; fb_main[3] = fb_main[3] + Cb[4] * g[3];
-            }
-            {
-                const T fr[4] = {a.alpha, beta_r, u[0], u[1]};
-                T g[4];
-                grad(5, fr, g);
-                fb_main[0] = fb_main[0] + Cb[5] * g[0];
-                brb = Cb[5] * g[1];
-                fb_main[2] = fb_main[2] + Cb[5] * g[2]; fb_main[3] = fb_main[3] + Cb[5] * g[3];
-            }
-            ab.alpha = ab.alpha + fb_main[0]; ab.beta = ab.beta + fb_main[1];
-            ub[0] = ub[0] + fb_main[2]; ub[1] = ub[1] + fb_main[3];
-            ub[2] = ub[2] + (0.01f * 6.0f * kDeg) * Cb[5];
-            // P_CZ(alpha_x, 0, 0, 0) = z0 + z1 a + z2 a^2 + z3 a^3
-            const float z1 = tab.coef(2, 0), z2 = tab.coef(2, 4), z3 = tab.coef(2, 14);
-            const float hb = b4 * 0.5f;
-            const T arb = (hb * Cb[3]) * (z1 + (2.0f * z2) * alpha_r + (3.0f * z3) * (alpha_r * alpha_r));
-            const T alb = -((hb * Cb[3]) * (z1 + (2.0f * z2) * alpha_l + (3.0f * z3) * (alpha_l * alpha_l)));
-            // the three atan2(y_x, ux)
-            T uxb = T(0.f);
-            auto atan2_bar = [&](const T& y, const T& bar, T& yb) {
-                const T iden = 1.0f / (ux * ux + y * y);
-                yb = bar * ux * iden;
-                uxb = uxb - bar * y * iden;
-            };
-            T yeb, ylb, yrb;
-            atan2_bar(ye, aeb, yeb); atan2_bar(yl, alb, ylb); atan2_bar(yr, arb, yrb);
-            ab.vr[0] = ab.vr[0] + uxb;
-            ab.vr[2] = ab.vr[2] + yeb + ylb + yrb;
-            wb[1] = wb[1] + arm * yeb;
-            wb[0] = wb[0] + b4 * (yrb - ylb);
-            // beta_r = asin(vy / |(vr0, vy, vr2)|_eps)
-            const T tbar = brb / m_sqrt(1.0f - tb * tb);
-            T vyb = tbar / nb;
-            const T sb2 = (-(tbar * tb) / nb) * (0.5f / nb);   // adjoint of the sum of squares
-            ab.vr[0] = ab.vr[0] + 2.0f * a.vr[0] * sb2;
-            vyb = vyb + 2.0f * vy * sb2;
-            ab.vr[2] = ab.vr[2] + 2.0f * a.vr[2] * sb2;
-            ab.vr[1] = ab.vr[1] + vyb;
-            wb[2] = wb[2] - arm * vyb;
+            poly_vjp(P, a, x, u, Cb, ab, wb, ub, grad);
         } else {  // DefaultModel (coefficient_models.py:41-78)
             static_assert(MODEL == AC_MODEL_DEFAULT, "adjoint: default, linear and cubic-fit models");
             ab.alpha = ab.alpha + (-0.6f * a.alpha) * Cb[0] + (-5.0f) * Cb[2];

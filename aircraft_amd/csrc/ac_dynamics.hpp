@@ -50,7 +50,7 @@ struct DevParams {
 constexpr float kDeg = 0.017453292519943295f;  // pi/180
 enum { AC_ROWS_PLAIN = 0, AC_ROWS_DEFECT = 1, AC_ROWS_IMPLICIT = 2 };
 
-constexpr int kPolyTabRows = 42, kPolyTabFloats = kPolyTabRows * 16;
+constexpr int kPolyTabRows = 66, kPolyTabFloats = kPolyTabRows * 16;  // 18 value + 24 gradient + 24 second-derivative rows
 struct Row16 { float c[16]; };
 struct PolyTab {
     const AC_CONSTANT float* t;
@@ -95,16 +95,21 @@ struct PolyTab {
     }
     static constexpr int value_row(int k, int part) { return 3 * k + part; }
     static constexpr int grad_row(int k, int v) { return 18 + 4 * k + v; }
+    // second derivatives of fit k: entries e = 0..9 = (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3), each linear in f
+    // ([c, c_f0, c_f1, c_f2, c_f3]); row r holds the entries 3 r .. 3 r + 2
+    static constexpr int hess_row(int k, int r) { return 42 + 4 * k + r; }
 };
 // host side of the layout
 inline void poly_pack_tables(const float* coef /*[6][34]*/, const float* intercept /*[6]*/, const float* grad /*[6][4][15]*/,
-                             float* tab /*[kPolyTabFloats]*/) {
+                             const float* hess /*[6][10][5]*/, float* tab /*[kPolyTabFloats]*/) {
     for (int i = 0; i < kPolyTabFloats; ++i) tab[i] = 0.f;
     for (int k = 0; k < 6; ++k) {
         tab[k * 48] = intercept[k];
         for (int q = 0; q < 34; ++q) tab[k * 48 + 1 + q] = coef[k * 34 + q];
         for (int v = 0; v < 4; ++v)
             for (int q = 0; q < 15; ++q) tab[(18 + k * 4 + v) * 16 + q] = grad[(k * 4 + v) * 15 + q];
+        for (int e = 0; e < 10; ++e)
+            for (int t = 0; t < 5; ++t) tab[(42 + k * 4 + e / 3) * 16 + 5 * (e % 3) + t] = hess[(k * 10 + e) * 5 + t];
     }
 }
 
@@ -331,6 +336,59 @@ inline void poly_gradient_tables(const float* coef /*[6][34]*/, float* grad /*[6
                 }
         for (int v = 0; v < 4; ++v)
             for (int q = 0; q < 15; ++q) grad[(k * 4 + v) * 15 + q] = (float)g[v][q];
+    }
+}
+
+// Host side of the second-derivative part of DevParams::poly_tab: the gradient tables differentiated once more.  Entry (v, q),
+// v <= q, of fit k is linear in f: hess[k][e] = [c, c_f0 .. c_f3].
+inline void poly_hessian_tables(const float* grad /*[6][4][15]*/, float* hess /*[6][10][5]*/) {
+    for (int k = 0; k < 6; ++k) {
+        int e = 0;
+        for (int v = 0; v < 4; ++v)
+            for (int q = v; q < 4; ++q, ++e) {
+                const float* g = grad + (k * 4 + v) * 15;  // d P_k / d f_v over [1, f_0..f_3, f_a f_b (a <= b)]
+                double h[5] = {(double)g[1 + q], 0, 0, 0, 0};
+                int idx = 5;
+                for (int a = 0; a < 4; ++a)
+                    for (int b = a; b < 4; ++b, ++idx) {  // d (f_a f_b) / d f_q = [a == q] f_b + [b == q] f_a
+                        if (a == q) h[1 + b] += (double)g[idx];
+                        if (b == q) h[1 + a] += (double)g[idx];
+                    }
+                for (int t = 0; t < 5; ++t) hess[(k * 10 + e) * 5 + t] = (float)h[t];
+            }
+    }
+}
+
+// Second derivatives of the fits ks[0..NOUT) at the primal point f (entry order: PolyTab::hess_row), rows streamed two at a time
+// like poly_value_grad's.
+template <int NOUT>
+AC_DI void poly_hess(const DevParams& P, const int (&ks)[NOUT], const float f[4], float h[NOUT][10]) {
+    const PolyTab tab(P);
+    constexpr int NI = 2 * NOUT;  // item = (fit, row pair)
+    Row16 c0 = tab.row(PolyTab::hess_row(ks[0], 0)), c1 = tab.row(PolyTab::hess_row(ks[0], 1));
+    PolyTab::arrive(c0, c1);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        Row16 n0 = c0, n1 = c1;
+        if (i + 1 < NI) {
+            n0 = tab.row(PolyTab::hess_row(ks[(i + 1) >> 1], 2 * ((i + 1) & 1)));
+            n1 = tab.row(PolyTab::hess_row(ks[(i + 1) >> 1], 2 * ((i + 1) & 1) + 1));
+        }
+        const int o = i >> 1, e0 = 6 * (i & 1);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float a = fmaf(c0.c[5 * j + 4], f[3], fmaf(c0.c[5 * j + 3], f[2], fmaf(c0.c[5 * j + 2], f[1], fmaf(c0.c[5 * j + 1], f[0], c0.c[5 * j]))));
+            AC_OPAQUE_V(a);
+            h[o][e0 + j] = a;
+            if (e0 + 3 + j < 10) {
+                float b = fmaf(c1.c[5 * j + 4], f[3], fmaf(c1.c[5 * j + 3], f[2], fmaf(c1.c[5 * j + 2], f[1], fmaf(c1.c[5 * j + 1], f[0], c1.c[5 * j]))));
+                AC_OPAQUE_V(b);
+                h[o][e0 + 3 + j] = b;
+            }
+        }
+        AC_SCHED_FENCE();
+        if (i + 1 < NI) PolyTab::arrive(n0, n1);
+        c0 = n0; c1 = n1;
     }
 }
 

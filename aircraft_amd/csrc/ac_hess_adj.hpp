@@ -143,6 +143,108 @@ template <bool TILE> struct AdjTensorCoeffsT : HessTensorCoeffs {
         ub[2] += (-0.1f * 6.0f * kDeg) * Cb[5];
     }
 };
+// Cubic fits for the reverse sweep in duals, through PRIMAL tables.  A first-order dual of a fit is its value and gradient at
+// the primal point, a dual of its gradient the gradient and the second derivatives there — none of which depends on the
+// direction.  Pushing duals through the 34 monomials and the gradient tables instead (AdjAnalyticCoeffs<POLY>, what the host
+// build checks) costs ~2 700 instructions per stage in each of the 16 direction waves of 64 units.  Here the four waves of a
+// workgroup (four direction groups of the same units) evaluate value, gradient and second derivatives of the six fits ONCE per
+// stage of the forward sweep, a quarter each (AnalyticCoeffs<POLY, SHARED>'s split), into LDS — [4 stages][90 rows][64 lanes],
+// 92 KB beside the 61 KB of stage states — behind one barrier; every later evaluation of that stage (the forward value, the
+// recomputation and the adjoint in the reverse sweep) reads rows.  Row 15 k + (0 | 1..4 | 5..14) = value | gradient | second
+// derivatives (PolyTab::hess_row order) of fit k at its own point: (alpha, beta, da, de) for k < 4, (alpha_e, ..) for the
+// elevator fit, (alpha, beta_r, ..) for the rudder fit.
+constexpr int kAdjPolyRows = 90, kAdjPolyFloats = 4 * kAdjPolyRows * 64;
+struct AdjPolyTabCoeffs {
+    static constexpr int kModel = AC_MODEL_POLY;
+    static constexpr bool kFusedTangent = false;
+    float* tl;   // LDS base + lane
+    int wave;    // this wave's quarter (wave-uniform)
+    int stage, step;
+    AC_DI AdjPolyTabCoeffs(float* lds, int wave_) : tl(lds + (threadIdx.x & 63)), wave(wave_), stage(0), step(0) {}
+    AC_DI void set_stage(int s) { stage = s; ++step; }
+    AC_DI bool forward_sweep() const { return step <= 4; }  // set_stage calls 1..4: the forward sweep (stages 0..3)
+    AC_DI const float* rows() const { return tl + stage * (kAdjPolyRows * 64); }
+    // write value, gradient and second derivatives of the fits ks[] at the float point f
+    template <int NOUT> AC_DI void tabulate(const DevParams& P, const int (&ks)[NOUT], const float f[4]) {
+        float val[NOUT], g[NOUT][4], h[NOUT][10];
+        poly_value_grad<NOUT>(P, ks, f, val, g);
+        poly_hess<NOUT>(P, ks, f, h);
+        float* r = tl + stage * (kAdjPolyRows * 64);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            float* rk = r + ks[o] * 15 * 64;
+            rk[0] = val[o];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) rk[(1 + v) * 64] = g[o][v];
+#pragma unroll
+            for (int e = 0; e < 10; ++e) rk[(5 + e) * 64] = h[o][e];
+        }
+    }
+    template <int N>
+    AC_DI void operator()(const DevParams& P, const AeroPre<Dual<N>>& a, const Dual<N> x[13], const Dual<N> u[7], Dual<N> C[6]) {
+        typedef Dual<N> T;
+        const T* w = &x[10];
+        const float eps = P.p.epsilon, arm = P.p.rudder_moment_arm, b4 = P.p.b * 0.25f;
+        const T ux = a.vr[0] + eps;
+        const T alpha_e = m_atan2(a.vr[2] + arm * w[1], ux);
+        const T alpha_l = m_atan2(a.vr[2] - b4 * w[0], ux);
+        const T alpha_r = m_atan2(a.vr[2] + b4 * w[0], ux);
+        const T vy = a.vr[1] - arm * w[2];
+        const T beta_r = m_asin(vy / m_sqrt(a.vr[0] * a.vr[0] + vy * vy + a.vr[2] * a.vr[2] + eps));
+        if (forward_sweep()) {
+            if (wave < 2) {
+                const float f[4] = {a.alpha.v, a.beta.v, u[0].v, u[1].v};
+                const int ks[2] = {2 * wave, 2 * wave + 1};
+                tabulate<2>(P, ks, f);
+            } else {
+                const bool el = wave == 2;
+                const float f[4] = {el ? alpha_e.v : a.alpha.v, el ? a.beta.v : beta_r.v, u[0].v, u[1].v};
+                const int ks[1] = {el ? 4 : 5};
+                tabulate<1>(P, ks, f);
+            }
+            __syncthreads();
+        }
+        const float* r = rows();
+        const T* fm[4] = {&a.alpha, &a.beta, &u[0], &u[1]};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const T* f0 = k == 4 ? &alpha_e : fm[0];
+            const T* f1 = k == 5 ? &beta_r : fm[1];
+            const float* rk = r + k * 15 * 64;
+            C[k].v = rk[0];
+            const float g0 = rk[1 * 64], g1 = rk[2 * 64], g2 = rk[3 * 64], g3 = rk[4 * 64];
+#pragma unroll
+            for (int i = 0; i < N; ++i) C[k].d[i] = fmaf(g0, f0->d[i], fmaf(g1, f1->d[i], fmaf(g2, u[0].d[i], g3 * u[1].d[i])));
+        }
+        C[3] = C[3] + (b4 * 0.5f) * (poly_cz_alpha_only(P, alpha_r) - poly_cz_alpha_only(P, alpha_l));
+        C[5] = C[5] + (0.01f * 6.0f * kDeg) * u[2];
+    }
+    template <int N>
+    AC_DI void vjp(const DevParams& P, const AeroPre<Dual<N>>& a, const Dual<N> x[13], const Dual<N> u[7], const Dual<N> Cb[6],
+                   AeroBar<Dual<N>>& ab, Dual<N> wb[3], Dual<N> ub[7]) const {
+        typedef Dual<N> T;
+        const float* r = rows();
+        // the gradient of fit k at its point f as a dual: (g_v, sum_q h_vq df_q)
+        auto grad = [&](int k, const T f[4], T g[4]) {
+            const float* rk = r + k * 15 * 64;
+            float h[4][4];
+            int e = 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int q = v; q < 4; ++q, ++e) { h[v][q] = rk[(5 + e) * 64]; h[q][v] = h[v][q]; }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                g[v].v = rk[(1 + v) * 64];
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    g[v].d[i] = fmaf(h[v][0], f[0].d[i], fmaf(h[v][1], f[1].d[i], fmaf(h[v][2], f[2].d[i], h[v][3] * f[3].d[i])));
+            }
+        };
+        poly_vjp(P, a, x, u, Cb, ab, wb, ub, grad);
+    }
+};
+
 template <int MODEL> struct AdjProvider { typedef AdjAnalyticCoeffs<MODEL> type; };
 template <> struct AdjProvider<AC_MODEL_NN> { typedef AdjTensorCoeffsT<false> type; };
 typedef AdjTensorCoeffsT<false> AdjTensorCoeffs;
@@ -199,6 +301,15 @@ __global__ __launch_bounds__(kBlock) void k_step_hess_rev(const DevParams P, con
 #else
             __shared__ float tensor_tile[kAdjTileFloats];
             return AdjTensorCoeffsT<true>(stage_tensors, ua, tensor_tile);
+#endif
+        }
+        else if constexpr (MODEL == AC_MODEL_POLY) {
+#ifdef AC_HESS_POLY_DUALS  // (A/B flavour: duals through the monomials and the gradient tables in every direction wave)
+            return AdjAnalyticCoeffs<MODEL>(stage_tensors, ua);
+#else
+            static_assert(kBlock / 64 == 4, "four direction waves per workgroup");
+            __shared__ float poly_points[kAdjPolyFloats];
+            return AdjPolyTabCoeffs(poly_points, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
 #endif
         }
         else return typename AdjProvider<MODEL>::type(stage_tensors, ua);

@@ -320,9 +320,10 @@ int ac_set_linear(ac_handle* h, const float* W) {
 int ac_set_poly(ac_handle* h, const float* coef, const float* intercept) {
     if (!h || !coef || !intercept) return AC_ERR_BAD_ARG;
     AC_ENTER(h);
-    float tab[kPolyTabFloats], grad[6 * 4 * 15];
+    float tab[kPolyTabFloats], grad[6 * 4 * 15], hess[6 * 10 * 5];
     poly_gradient_tables(coef, grad);
-    poly_pack_tables(coef, intercept, grad, tab);
+    poly_hessian_tables(grad, hess);
+    poly_pack_tables(coef, intercept, grad, hess, tab);
     if (!h->d_poly_tab) AC_HIP(hipMalloc((void**)&h->d_poly_tab, sizeof(tab)));
     AC_HIP(hipMemcpy(h->d_poly_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
     h->dp.poly_tab = h->d_poly_tab;

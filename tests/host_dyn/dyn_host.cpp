@@ -114,9 +114,10 @@ extern "C" int host_dyn_adjoint(const ac_params* p, const float* linear_W, const
     if (linear_W) for (int i = 0; i < 36; ++i) P.linear_W[i] = linear_W[i];
     alignas(64) static thread_local float tab[kPolyTabFloats];
     if (poly_coef && poly_intercept) {
-        float gradt[6 * 4 * 15];
+        float gradt[6 * 4 * 15], hesst[6 * 10 * 5];
         poly_gradient_tables(poly_coef, gradt);
-        poly_pack_tables(poly_coef, poly_intercept, gradt, tab);
+        poly_hessian_tables(gradt, hesst);
+        poly_pack_tables(poly_coef, poly_intercept, gradt, hesst, tab);
         P.poly_tab = tab;
     }
     if (P.p.substeps > 1) return -1;
@@ -147,9 +148,10 @@ extern "C" int host_dyn_sens(const ac_params* p, const float* linear_W, const fl
     if (linear_W) for (int i = 0; i < 36; ++i) P.linear_W[i] = linear_W[i];
     alignas(64) static thread_local float tab[kPolyTabFloats];
     if (poly_coef && poly_intercept) {
-        float grad[6 * 4 * 15];
+        float grad[6 * 4 * 15], hess[6 * 10 * 5];
         poly_gradient_tables(poly_coef, grad);
-        poly_pack_tables(poly_coef, poly_intercept, grad, tab);
+        poly_hessian_tables(grad, hess);
+        poly_pack_tables(poly_coef, poly_intercept, grad, hess, tab);
         P.poly_tab = tab;
     }
     if (what == 0 && P.p.substeps > 1) return -1;
@@ -160,4 +162,28 @@ extern "C" int host_dyn_sens(const ac_params* p, const float* linear_W, const fl
     AC_CASE(AC_MODEL_QUAD, 2) AC_CASE(AC_MODEL_QUAD, 4) AC_CASE(AC_MODEL_QUAD, 8)
 #undef AC_CASE
     return -2;
+}
+
+// Value, gradient and second derivatives of fit k at the points F [4][n] through the PACKED tables and the device's own
+// streaming evaluators (poly_value_grad, poly_hess): out [15][n] = val, g[4], h[10] (entry order: PolyTab::hess_row).
+extern "C" int host_poly_point(const float* poly_coef, const float* poly_intercept, int k, const float* F, long n, float* out) {
+    DevParams P{};
+    alignas(64) static thread_local float tab[kPolyTabFloats];
+    float grad[6 * 4 * 15], hess[6 * 10 * 5];
+    poly_gradient_tables(poly_coef, grad);
+    poly_hessian_tables(grad, hess);
+    poly_pack_tables(poly_coef, poly_intercept, grad, hess, tab);
+    P.poly_tab = tab;
+    if (k < 0 || k > 5) return -1;
+    for (long u = 0; u < n; ++u) {
+        const float f[4] = {F[u], F[n + u], F[2 * n + u], F[3 * n + u]};
+        const int ks[1] = {k};
+        float val[1], g[1][4], h[1][10];
+        poly_value_grad<1>(P, ks, f, val, g);
+        poly_hess<1>(P, ks, f, h);
+        out[u] = val[0];
+        for (int v = 0; v < 4; ++v) out[(1 + v) * n + u] = g[0][v];
+        for (int e = 0; e < 10; ++e) out[(5 + e) * n + u] = h[0][e];
+    }
+    return 0;
 }

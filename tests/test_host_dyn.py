@@ -20,7 +20,7 @@ CSRC = os.path.join(os.path.dirname(HERE), "..", "aircraft_amd", "csrc")
 
 def _lib():
     src = os.path.join(HERE, "dyn_host.cpp")
-    deps = [src] + [os.path.join(CSRC, f) for f in ("ac_math.hpp", "ac_dynamics.hpp")]
+    deps = [src] + [os.path.join(CSRC, f) for f in ("ac_math.hpp", "ac_dynamics.hpp", "ac_adjoint.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         # -ffp-contract=off: the tolerance below then holds for the least favourable (unfused) rounding
         subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", SO, src], check=True)
@@ -126,3 +126,44 @@ def test_reverse_sweep_gradient_and_hessian_on_host(model, normalise, stall, N):
     assert rel.max() < 1e-3, (int(rel.argmax()), float(rel.max()))
     assert np.abs(Hm - Hm.transpose(1, 0, 2)).max() <= 2e-4 * np.abs(Hm).max()
     assert not Hm[:3].any() and not Hm[16:19].any()
+
+
+def test_cubic_fit_value_gradient_and_second_derivative_tables():
+    """The host-derived gradient and second-derivative tables of the cubic fits (ac_set_poly uploads them; the sensitivity and
+    second-order kernels stream them) evaluated by the device's own row-streaming code, against the polynomial itself in
+    float64: sklearn's monomial order, derivatives by the product rule."""
+    import itertools
+    ac = make_aircraft("poly")
+    d = ac.coefficient_model.oracle_data()
+    coef = np.ascontiguousarray(d["coef"], dtype=np.float32)
+    icpt = np.ascontiguousarray(d["intercept"], dtype=np.float32)
+    L = _lib()
+    fp = C.POINTER(C.c_float)
+    L.host_poly_point.restype = C.c_int
+    L.host_poly_point.argtypes = [fp, fp, C.c_int, fp, C.c_long, fp]
+    rng = np.random.default_rng(5)
+    n = 200
+    F = np.ascontiguousarray(rng.uniform(-0.4, 0.4, (4, n)), dtype=np.float32)
+    combos = [c for deg in (1, 2, 3) for c in itertools.combinations_with_replacement(range(4), deg)]
+    assert len(combos) == 34
+    F64 = F.astype(np.float64)
+    pairs = [(v, q) for v in range(4) for q in range(v, 4)]
+    for k in range(6):
+        out = np.zeros((15, n), dtype=np.float32)
+        assert L.host_poly_point(coef.ctypes.data_as(fp), icpt.ctypes.data_as(fp), k, F.ctypes.data_as(fp), n, out.ctypes.data_as(fp)) == 0
+        val = np.full(n, float(icpt[k])); g = np.zeros((4, n)); h = np.zeros((4, 4, n))
+        for t, cmb in enumerate(combos):
+            c = float(coef[k, t])
+            val += c * np.prod([F64[i] for i in cmb], axis=0)
+            for pos, v in enumerate(cmb):  # d/df_v: drop one factor
+                rest = cmb[:pos] + cmb[pos + 1:]
+                g[v] += c * (np.prod([F64[i] for i in rest], axis=0) if rest else 1.0)
+                for pos2, q in enumerate(rest):  # d2/df_v df_q: drop another
+                    rest2 = rest[:pos2] + rest[pos2 + 1:]
+                    h[v, q] += c * (np.prod([F64[i] for i in rest2], axis=0) if rest2 else 1.0)
+        scale = max(1.0, np.abs(coef[k]).max())
+        assert np.abs(out[0] - val).max() < 2e-6 * scale
+        assert np.abs(out[1:5] - g).max() < 5e-6 * scale
+        for e, (v, q) in enumerate(pairs):
+            assert np.abs(out[5 + e] - h[v, q]).max() < 1e-5 * scale, (k, v, q)
+            assert np.abs(h[v, q] - h[q, v]).max() < 1e-12 * scale
