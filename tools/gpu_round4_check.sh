@@ -7,6 +7,8 @@ rm -f gpurun_out/parity_report.jsonl
 rm -rf gpurun_out/r4_prof_final gpurun_out/r4_pmc_final gpurun_out/r4_pmc_cfg2 gpurun_out/r4_prof_cfg2_256 gpurun_out/r4_prof_cfg2_4096
 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > gpurun_out/r4_pytest_gpu_final.log 2>&1 || true
 tail -3 gpurun_out/r4_pytest_gpu_final.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r4_smoke.log 2>&1 || echo "smoke FAILED"
+tail -2 gpurun_out/r4_smoke.log
 python bench.py > gpurun_out/r4_bench_final.json 2> gpurun_out/r4_bench_final.err || echo "bench rc=$?"
 cat gpurun_out/r4_bench_final.json
 AIRCRAFT_BENCH_ONE_GPU=1 AIRCRAFT_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 > gpurun_out/r4_bench_n2_rehearsal.json 2> gpurun_out/r4_bench_n2_rehearsal.err || true
