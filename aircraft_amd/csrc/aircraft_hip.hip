@@ -466,13 +466,15 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
         }
     }
     // LDS plan: everything resident if it fits; otherwise the largest layers stream through a 2-slot ring.
-    auto plan_lds = [&](MlpPlan& pl) -> int {
+    // force_stream: the largest size class goes through the ring even when everything would fit (plan_rev of a net with ONE
+    // hidden product: the reverse-sweep kernel sequences its hidden and transposed blocks through the ring by hand)
+    auto plan_lds = [&](MlpPlan& pl, bool force_stream = false) -> int {
         const int n_layers = pl.n_layers;  // (plan_rev carries more blocks than the net has layers)
         pl.n_streamed = 0; pl.first_streamed = -1;
         int total = 0;
         for (int l = 0; l < n_layers; ++l) total += pl.bytes[l];
         for (int l = 0; l < n_layers; ++l) pl.lds_off[l] = 0;
-        if (total <= kLdsBudget) {
+        if (total <= kLdsBudget && !force_stream) {
             int off = 0;
             for (int l = 0; l < n_layers; ++l) { pl.lds_off[l] = off; off += pl.bytes[l]; }
             pl.n_streamed = 0; pl.first_streamed = -1; pl.lds_total = off;
@@ -523,7 +525,7 @@ int ac_set_mlp(ac_handle* h, int n_layers, const int* widths, const int* act, co
         }
         pr.n_layers = n_layers + n_hid;
         // the kernel expects the hidden and the transposed blocks to stream (one size class) and the edge blocks to stay
-        rev_ok = plan_lds(pr) == AC_OK && pr.n_streamed == 2 * n_hid && pr.lds_off[0] >= 0 && pr.lds_off[n_layers - 1] >= 0;
+        rev_ok = plan_lds(pr, /*force_stream=*/true) == AC_OK && pr.n_streamed == 2 * n_hid && pr.lds_off[0] >= 0 && pr.lds_off[n_layers - 1] >= 0;
     }
     // "MFMA off": weight image of the tiled vector-ALU engine, k-major [K][N] per layer (the last layer transposed [8][K]),
     // hidden widths zero-padded to 32 or 64.  Nets it does not cover (wider than 64, or a single layer after the fold)

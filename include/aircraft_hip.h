@@ -204,7 +204,7 @@ int ac_quat_rows_f32(ac_handle* h, int mode, const float* X, const float* Xdot, 
  * (the reference's largest time sink, todo.md:102).  lambda [13][n] (device) are the multipliers of the 13 rows of F.
  * Exact second-order forward mode of the same fp32 arithmetic as ac_step_f32.  Rows/columns of p (0-2) and of controls
  * without effect are zero.  All force models.  The MLP surrogate evaluates its second-derivative tensor with the MFMA
- * engine (hidden width 128 with two or three hidden 128 x 128 products: forward tangents + a reverse sweep through the
+ * engine (hidden width 128 with one to three hidden 128 x 128 products: forward tangents + a reverse sweep through the
  * transposed blocks, csrc/ac_hess_rev.hpp, which also keeps per-wave layer states in a handle-owned scratch of
  * CUs x 4 x (1 + 6 hidden products) x 8 KiB; otherwise one slab per derivative, csrc/ac_hess_nn.hpp)
  * into a handle-owned workspace of n*504 floats: size it once with ac_reserve_hess_workspace(h, n_max) — a
@@ -215,7 +215,7 @@ int ac_quat_rows_f32(ac_handle* h, int mode, const float* X, const float* Xdot, 
  * per-sub-step blocks: d2/dz2 = sum_s T_s' H_s T_s with T_s = d(x_{s-1}, u, dt/ns)/dz carried by the first-order chain and the
  * multipliers pulled back through the later sub-steps (mu_{s-1} = A_s' mu_s); it needs (559 ns + 481) n floats more of the
  * same reserved workspace, sized for the handle's sub-step count at the time of ac_reserve_hess_workspace.
- * AC_ERR_UNSUPPORTED for an MLP wider than 64 with use_mfma = 0 unless it has two or three hidden 128 x 128 products (the
+ * AC_ERR_UNSUPPORTED for an MLP wider than 64 with use_mfma = 0 unless it has one to three hidden 128 x 128 products (the
  * reverse-sweep kernel has a cross-lane flavour, the slab-per-derivative kernel at that width has not).  Hout is zero-filled by the call (hipMemsetAsync on `stream`) before the active block is
  * written.  ac_shoot_hess_f32 reads rollout-shaped X [H(+1)][13][B], U [H][7][B], lambda [H][13][B] in place and writes
  * Hout [H][21][21][B]. */

@@ -46,7 +46,8 @@ def test_hessian_matches_finite_differences_of_exact_jacobians(gpu, model, norma
 
 
 @pytest.mark.parametrize("hidden,normalise,use_mfma", [((64, 64, 64), True, True), (None, False, True), ((128, 128, 128, 128), True, True),
-                                                       ((32, 32), True, False), ((128, 100, 128), True, False)])
+                                                       ((32, 32), True, False), ((128, 100, 128), True, False),
+                                                       ((128, 128), True, False), ((128, 128), False, True)])
 def test_hessian_mlp_surrogate(gpu, hidden, normalise, use_mfma):
     """MLP surrogate: stage tensors (y, J, d2y/dz dz) from the MFMA engine's second-order mode, then the same
     second-order forward-mode kernel.  hidden=None is the reference's own network (Linear-tanh-Linear)."""
@@ -150,13 +151,14 @@ def test_hessian_workspace_must_be_reserved_through_the_abi(gpu):
 
 
 def test_wide_valu_flavour_is_refused(gpu):
-    """Second-order blocks at width > 64 with use_mfma = 0 exist for nets with two or three hidden 128 x 128 products only
-    (the reverse-sweep kernel's cross-lane flavour, include/aircraft_hip.h; test_hessian_mlp_surrogate covers one): a net with
-    ONE such product has no instance, and the call must fail loudly, not fall back."""
+    """Second-order blocks at width > 64 with use_mfma = 0 exist for nets with one to three hidden 128 x 128 products (the
+    reverse-sweep kernel's cross-lane flavour, include/aircraft_hip.h; test_hessian_mlp_surrogate covers two): a net with ONE
+    hidden LAYER of that width has no product to sweep back through and no instance of the slab kernel, and the call must fail
+    loudly, not fall back."""
     import torch
     from aircraft_amd import AircraftHipError
     from tests.helpers import make_aircraft
-    ac = make_aircraft("nn", hidden=(128, 128), use_mfma=False)
+    ac = make_aircraft("nn", hidden=(128,), use_mfma=False)
     x = torch.zeros((13, 4), device=gpu); x[3] = 30.0; x[9] = 1.0
     with pytest.raises(AircraftHipError, match="UNSUPPORTED"):
         ac.step_hess(x, torch.zeros((7, 4), device=gpu), 0.01, torch.ones((13, 4), device=gpu))
@@ -291,12 +293,12 @@ def test_hessian_composed_over_substeps(gpu, model, hidden, substeps, normalise)
     ((128, 128, 128, 128), 1, 70, "rev"),    # tanh on the LAST layer as well: R_top carries act'(p), + act''(p) J J
     ((100, 128, 90), 0, 64, "rev"),          # two hidden products, widths below the padded 128
     ((128, 128, 128, 128), 0, 7, "rev"),     # fewer units than one wave
-    ((128, 128), 0, 96, "slabs"),            # one hidden product: the whole plan is resident, the slab-per-derivative kernel stays
+    ((128, 128), 0, 96, "rev"),              # one hidden product: its block and the transposed one take turns in the ring
     ((128, 128, 128, 128, 128), 0, 96, "slabs"),  # four hidden products: more blocks than the reverse plan holds
 ])
 def test_width_128_stage_tensors_by_reverse_sweep(gpu, hidden, act_last, n, kernel):
     """Width 128 on the matrix cores: the stage tensors come from k_nn_stage_tensors_rev (forward tangents, reverse sweep through
-    the transposed hidden blocks, per-unit contraction; ac_hess_rev.hpp) for nets with two or three hidden products, from the
+    the transposed hidden blocks, per-unit contraction; ac_hess_rev.hpp) for nets with one to three hidden products, from the
     slab-per-derivative kernel otherwise; both against central differences of the oracle's exact float64 Jacobians."""
     import torch
 
