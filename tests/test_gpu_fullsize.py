@@ -463,3 +463,42 @@ def test_cfg5_full_size_graph_replay_of_1000_solves(gpu, model):
     assert qerr < 1e-5
     if model == "poly":    # the real aerodynamics settle into the steady glide (every instance the same one)
         assert w_end < 0.05 and float(hist[-1, 3:6].norm(dim=0).std()) < 0.05
+
+
+@pytest.mark.parametrize("model", ["poly", "default", "real"])
+def test_reference_models_at_the_headline_size(gpu, model):
+    """The models the reference itself ships, at cfg3's size (B = 4096 x H = 50 = 204 800 units, 3 200 workgroups whose four
+    direction waves exchange primal work through LDS behind barriers): every unit of a random sample against the float64
+    oracle, two runs bit-identical, halves of the batch bit-identical to the whole (other workgroups, other rounds), and the
+    implicit rows (derivative kernel, same exchange) against the same oracle."""
+    import torch
+    from aircraft_amd.control import MultipleShooting
+
+    ac = make_aircraft("nn" if model == "real" else model)
+    ms = MultipleShooting(system=ac, dt=0.01, num_nodes=50, opts={"quaternion": "integration"})
+    Xh, Uh, X, U = _problem(4096, 50, gpu, seed=7)
+    F, A, Bm, c = ms.linearise(X, U)
+    rng = np.random.default_rng(3)
+    k = rng.integers(0, 50, 1024); b = rng.integers(0, 4096, 1024)
+    k[:4] = (0, 0, 49, 49); b[:4] = (0, 4095, 0, 4095)
+    Xs = np.ascontiguousarray(Xh[k, :, b].T); Us = np.ascontiguousarray(Uh[k, :, b].T)
+    orc = make_oracle(ac)
+    Xr, Ar, Br, cr = orc.step_sens(Xs, Us, 0.01)
+    assert block_rel_err(F.cpu().numpy()[k, :, b].T, Xr) < 1e-5
+    for name, got, want in (("A", A.cpu().numpy()[k, :, :, b].transpose(1, 2, 0), Ar), ("B", Bm.cpu().numpy()[k, :, :, b].transpose(1, 2, 0), Br)):
+        e = unit_max_rel(got, want)
+        parity_report(f"headline_size[{model}]", block=name, units=int(e.size), unit_rel_max=float(e.max()))
+        assert e.max() < 1e-5, (model, name, int(e.argmax()), float(e.max()))
+    F2, A2, B2, c2 = ms.linearise(X, U)
+    assert torch.equal(F2, F) and torch.equal(A2, A) and torch.equal(B2, Bm)
+    for lo, hi in ((0, 2048), (2048, 4096), (1000, 1100)):
+        Fh, Ah, Bh, ch = ms.linearise(X[:, :, lo:hi].contiguous(), U[:, :, lo:hi].contiguous())
+        assert torch.equal(Fh, F[:, :, lo:hi]) and torch.equal(Ah, A[:, :, :, lo:hi]) and torch.equal(Bh, Bm[:, :, :, lo:hi])
+    if model != "real":
+        # derivative kernel: f and its Jacobians at the nodes
+        xd, Fx, Fu = ac.state_derivative_sens(X[:50].permute(1, 0, 2).reshape(13, -1).contiguous(), U.permute(1, 0, 2).reshape(7, -1).contiguous())
+        flat = k * 4096 + b
+        fr, Fxr, Fur = orc.state_derivative_sens(Xs, Us)
+        assert block_rel_err(xd.cpu().numpy()[:, flat], fr) < 2e-5
+        assert unit_max_rel(Fx.cpu().numpy()[:, :, flat], Fxr).max() < 1e-5
+        assert unit_max_rel(Fu.cpu().numpy()[:, :, flat], Fur).max() < 1e-5
