@@ -896,11 +896,7 @@ AC_DI void state_derivative(const DevParams& P, Coeffs& coeffs, const Dual<N> x[
         AeroPre<float> a;
         aero_pre(P, xv, a);
         float C[6];
-#ifdef AC_PROBE_NOLIN
-        for (int k = 0; k < 6; ++k) C[k] = a.alpha * (float)k;
-#else
         coeffs.linearise(P, a, xv, uv, C);
-#endif
         // stall factors (dynamics/aircraft.py:280-294) as coefficients of (dC, d alpha, d beta)
         float s2 = 1.f, k2a = 0.f, k2b = 0.f, s4 = 1.f, k4a = 0.f;
         float stall[2] = {1.f, 1.f};
